@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE in the build container.
+
+Usage (build container only; /root/reference does not exist on the GPU box):
+    python tests/golden/make_golden.py [--ref /root/reference]
+
+The reference's PyTorch definition of the OpenVision model is the vendored open_clip 2.26.1 under
+``src/convert_upload/open_clip`` (``model.CLIP``, ``loss.ClipLoss``).  Its package ``__init__``
+pulls torchvision/ftfy, which are absent offline, so it is imported per SURVEY.md §8c: a stub
+``torchvision.ops.misc.FrozenBatchNorm2d`` and a bare ``open_clip`` package whose ``__path__`` points at
+the vendored directory (skipping ``__init__.py``).  Only arrays (inputs + the reference's outputs)
+are written; weights are NOT stored — they are rebuilt from ``openvision_amd.synth.make_state_dict``.
+
+Files written (np.savez_compressed):
+  ops.npz                 LayerNorm / GELU(erf,tanh) / ResidualAttentionBlock of the reference on small inputs
+  tiny16_160.npz          Ti/16@160 + text-Ti: tokens after block 0 / last block, features, logits, loss
+  tiny16_160_testcat.npz  the 5 testcat PNGs (resized to 160, normalised) x 9 caption rows: cosine/probs/argsort
+  large14_224.npz         L/14@224 + text-L, B=2: features (fp32 and the reference's bf16 mode), token slices
+  small8_384.npz          S/8@384, B=1 (2305 tokens): features, token slices
+  cliploss_ws.npz         ClipLoss(local_loss=True) per-rank losses at world_size 2 and 8 over gloo
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from openvision_amd import config as ovcfg          # noqa: E402
+from openvision_amd import synth                    # noqa: E402
+
+
+def import_reference(ref_root: str):
+    import transformers  # noqa: F401  (must precede the torchvision stub)
+    tv = types.ModuleType("torchvision")
+    tvo = types.ModuleType("torchvision.ops")
+    tvm = types.ModuleType("torchvision.ops.misc")
+
+    class FrozenBatchNorm2d(torch.nn.Module):
+        pass
+
+    tvm.FrozenBatchNorm2d = FrozenBatchNorm2d
+    tv.ops, tvo.misc = tvo, tvm
+    sys.modules.update({"torchvision": tv, "torchvision.ops": tvo, "torchvision.ops.misc": tvm})
+    pkg = types.ModuleType("open_clip")
+    pkg.__path__ = [os.path.join(ref_root, "src/convert_upload/open_clip")]
+    sys.modules["open_clip"] = pkg
+    return (importlib.import_module("open_clip.model"), importlib.import_module("open_clip.loss"),
+            importlib.import_module("open_clip.transformer"))
+
+
+def build_ref(m, model_cfg, seed=0, cast_dtype=None):
+    model = m.CLIP(embed_dim=model_cfg["embed_dim"], vision_cfg=dict(model_cfg["vision_cfg"]),
+                   text_cfg=dict(model_cfg["text_cfg"]), cast_dtype=cast_dtype)
+    sd = synth.make_state_dict(model_cfg, seed)
+    model.load_state_dict(sd, strict=True)       # ov-zero-shot-test.py:54
+    model.eval()
+    if cast_dtype is not None:
+        m.convert_weights_to_lp(model, dtype=cast_dtype)   # factory.py:275-296 ('bf16' precision)
+    return model
+
+
+def tokens_after_blocks(model, images, which):
+    """Hidden states after selected resblocks of the vision tower (forward hooks on the reference)."""
+    outs, hooks = {}, []
+    for i in which:
+        hooks.append(model.visual.transformer.resblocks[i].register_forward_hook(
+            lambda mod, inp, out, i=i: outs.__setitem__(i, out.detach().float().clone())))
+    with torch.no_grad():
+        model.encode_image(images)
+    for h in hooks:
+        h.remove()
+    return outs
+
+
+def f32(t):
+    return t.detach().float().cpu().numpy().copy()
+
+
+def gen_ops(m, tr, out):
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(6, 192, generator=g) * 2.0 + 0.3
+    ln = tr.LayerNorm(192, eps=1e-6)     # the towers construct every LN with eps=1e-6 (transformer.py:458,491,499,537)
+    with torch.no_grad():
+        ln.weight.copy_(torch.randn(192, generator=g) * 0.1 + 1)
+        ln.bias.copy_(torch.randn(192, generator=g) * 0.1)
+    xg = torch.linspace(-6, 6, 193)
+    cfg = ovcfg.preset("vit-tiny-patch16-160")
+    sd = synth.make_state_dict(cfg, 0)
+    blk = tr.ResidualAttentionBlock(192, 3, 4.0, batch_first=True, norm_layer=lambda d: tr.LayerNorm(d, eps=1e-6))
+    p = "visual.transformer.resblocks.0."
+    blk.load_state_dict({k[len(p):]: v for k, v in sd.items() if k.startswith(p)}, strict=True)
+    blk.eval()
+    xb = torch.randn(2, 101, 192, generator=g)
+    with torch.no_grad():
+        np.savez_compressed(
+            out, ln_x=f32(x), ln_w=f32(ln.weight), ln_b=f32(ln.bias), ln_y=f32(ln(x)), ln_eps=np.float64(ln.eps),
+            gelu_x=f32(xg), gelu_erf=f32(torch.nn.GELU()(xg)), gelu_tanh=f32(torch.nn.GELU(approximate="tanh")(xg)),
+            blk_x=f32(xb), blk_y=f32(blk(xb)))
+
+
+def gen_tiny(m, lossmod, out):
+    cfg = ovcfg.preset("vit-tiny-patch16-160")
+    model = build_ref(m, cfg)
+    img = synth.make_images(4, 160, seed=11)
+    tok = synth.make_captions(4, 80, 32000, seed=11)
+    hs = tokens_after_blocks(model, img, [0, 11])
+    with torch.no_grad():
+        fi, ft = model.encode_image(img), model.encode_text(tok)
+        ni, nt, s = model(img, tok)
+        li, lt = model.get_logits(img, tok)
+        loss = lossmod.ClipLoss()(ni, nt, s)
+        conv = model.visual.conv1(img)
+    np.savez_compressed(out, images=f32(img), tokens=tok.numpy(), conv1=f32(conv), block0=f32(hs[0]), block11=f32(hs[11]),
+                        image_features=f32(fi), text_features=f32(ft), image_norm=f32(ni), text_norm=f32(nt),
+                        logit_scale_exp=f32(s), logits_per_image=f32(li), logits_per_text=f32(lt), loss=f32(loss))
+
+
+def load_testcat(ref_root, size, mean, std):
+    from PIL import Image
+    names = sorted(n for n in os.listdir(os.path.join(ref_root, "testcat")) if n.lower().endswith(".png"))
+    arr = []
+    for n in names:
+        im = Image.open(os.path.join(ref_root, "testcat", n)).convert("RGB")
+        im = im.resize((size, size), Image.BILINEAR)         # torchvision Resize on a PIL image
+        a = np.asarray(im, dtype=np.float32) / 255.0          # ToTensor
+        a = (a - np.asarray(mean, np.float32)) / np.asarray(std, np.float32)
+        arr.append(a.transpose(2, 0, 1))
+    return names, torch.from_numpy(np.stack(arr)).half().float()   # stored as fp16
+
+
+def gen_testcat(m, ref_root, out):
+    """Counterpart of ov-zero-shot-test.py:157-195 on formula weights.  The HF tokenizer is unavailable
+    offline, so the 9 'prompts' are committed token-id rows in the training format."""
+    cfg = ovcfg.preset("vit-tiny-patch16-160")
+    model = build_ref(m, cfg)
+    pp = ovcfg.DEFAULT_PREPROCESS
+    names, img = load_testcat(ref_root, 160, pp["mean"], pp["std"])
+    tok = synth.make_captions(9, 80, 32000, seed=7)
+    with torch.no_grad():
+        tf = model.encode_text(tok)
+        tf = tf / tf.norm(dim=-1, keepdim=True)
+        cos, probs = [], []
+        for i in range(img.shape[0]):                      # batch = 1 per image, as the script does
+            f = model.encode_image(img[i:i + 1])
+            f = f / f.norm(dim=-1, keepdim=True)
+            c = (f @ tf.T)[0]
+            cos.append(c)
+            probs.append((model.logit_scale.exp() * c).softmax(dim=-1))
+        cos, probs = torch.stack(cos), torch.stack(probs)
+    np.savez_compressed(out, names=np.array(names), images=img.numpy().astype(np.float16), tokens=tok.numpy(),
+                        cosine=f32(cos), probs=f32(probs), argsort=cos.argsort(dim=-1, descending=True).numpy(),
+                        best=probs.argmax(dim=-1).numpy())
+
+
+def gen_large(m, lossmod, out):
+    cfg = ovcfg.preset("vit-large-patch14-224")
+    model = build_ref(m, cfg)
+    img = synth.make_images(2, 224, seed=21).half().float()     # stored as fp16: run the reference on the stored values
+    tok = synth.make_captions(2, 80, 32000, seed=21)
+    hs = tokens_after_blocks(model, img, [0, 23])
+    with torch.no_grad():
+        fi, ft = model.encode_image(img), model.encode_text(tok)
+        ni, nt, s = model(img, tok)
+        loss = lossmod.ClipLoss()(ni, nt, s)
+    del model
+    # the reference's own bf16 mode: bf16 Linear/Conv/MHA/proj, fp32 LN via LayerNormFp32 (model.py:143,396-423)
+    mb = build_ref(m, cfg, cast_dtype=torch.bfloat16)
+    with torch.no_grad():
+        fib = mb.encode_image(img.to(torch.bfloat16))
+        ftb = mb.encode_text(tok)
+    np.savez_compressed(out, images=img.numpy().astype(np.float16), tokens=tok.numpy(),
+                        block0_head=f32(hs[0][:, :4]), block23_head=f32(hs[23][:, :4]), block23_tail=f32(hs[23][:, -2:]),
+                        image_features=f32(fi), text_features=f32(ft), image_norm=f32(ni), text_norm=f32(nt),
+                        loss=f32(loss), image_features_refbf16=f32(fib), text_features_refbf16=f32(ftb))
+
+
+def gen_small(m, out):
+    cfg = ovcfg.preset("vit-small-patch8-384")
+    model = build_ref(m, cfg)
+    img = synth.make_images(1, 384, seed=31).half().float()
+    hs = tokens_after_blocks(model, img, [0, 11])
+    with torch.no_grad():
+        fi = model.encode_image(img)
+    np.savez_compressed(out, images=img.numpy().astype(np.float16), block0_head=f32(hs[0][:, :4]),
+                        block11_head=f32(hs[11][:, :4]), block11_tail=f32(hs[11][:, -2:]), image_features=f32(fi))
+
+
+def _loss_worker(rank, ws, store, ref_root, feats, q):
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method=f"file://{store}", rank=rank, world_size=ws)
+    _, lossmod, _ = import_reference(ref_root)
+    img, txt, s = feats
+    b = img.shape[0] // ws
+    fn = lossmod.ClipLoss(local_loss=True, rank=rank, world_size=ws)
+    with torch.no_grad():
+        l = fn(img[rank * b:(rank + 1) * b], txt[rank * b:(rank + 1) * b], s)
+    q.put((rank, float(l)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def gen_cliploss(lossmod, ref_root, out):
+    import torch.multiprocessing as mp
+    g = torch.Generator().manual_seed(99)
+    n, e = 16, 192
+    img = torch.nn.functional.normalize(torch.randn(n, e, generator=g), dim=-1)
+    txt = torch.nn.functional.normalize(img * 0.6 + torch.randn(n, e, generator=g) * 0.1, dim=-1)
+    s = torch.tensor(1.0 / 0.07)
+    res = {"img": f32(img), "txt": f32(txt), "scale": f32(s),
+           "loss_ws1": f32(lossmod.ClipLoss()(img, txt, s))}
+    ctx = mp.get_context("spawn")
+    for ws in (2, 8):
+        with tempfile.TemporaryDirectory() as d:
+            q = ctx.Queue()
+            ps = [ctx.Process(target=_loss_worker, args=(r, ws, os.path.join(d, "store"), ref_root, (img, txt, s), q))
+                  for r in range(ws)]
+            [p.start() for p in ps]
+            got = dict(q.get(timeout=600) for _ in range(ws))
+            [p.join() for p in ps]
+        res[f"local_losses_ws{ws}"] = np.array([got[r] for r in range(ws)], dtype=np.float64)
+    np.savez_compressed(out, **res)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    torch.manual_seed(0)
+    torch.set_num_threads(os.cpu_count())
+    m, lossmod, tr = import_reference(a.ref)
+    jobs = {
+        "ops": lambda: gen_ops(m, tr, os.path.join(HERE, "ops.npz")),
+        "tiny": lambda: gen_tiny(m, lossmod, os.path.join(HERE, "tiny16_160.npz")),
+        "testcat": lambda: gen_testcat(m, a.ref, os.path.join(HERE, "tiny16_160_testcat.npz")),
+        "large": lambda: gen_large(m, lossmod, os.path.join(HERE, "large14_224.npz")),
+        "small": lambda: gen_small(m, os.path.join(HERE, "small8_384.npz")),
+        "cliploss": lambda: gen_cliploss(lossmod, a.ref, os.path.join(HERE, "cliploss_ws.npz")),
+    }
+    for k, fn in jobs.items():
+        if a.only and k not in a.only.split(","):
+            continue
+        print("generating", k, flush=True)
+        fn()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,114 @@
+"""CPU: the oracle (oracle/clip_ref.py) against the golden vectors the REFERENCE produced
+(tests/golden/make_golden.py).  This is what pins the oracle; fp32, tight tolerances."""
+import numpy as np
+import pytest
+import torch
+
+from openvision_amd import config as ovcfg, synth
+from oracle import clip_ref as R
+from conftest import golden
+
+T = torch.from_numpy
+
+
+def close(a, b, atol, rtol=1e-5):
+    a = a.detach().numpy() if isinstance(a, torch.Tensor) else a
+    np.testing.assert_allclose(a, b, atol=atol, rtol=rtol)
+
+
+def test_ops_layernorm_gelu_block():
+    g = golden("ops.npz")
+    assert float(g["ln_eps"]) == 1e-6
+    close(R.layer_norm(T(g["ln_x"]), T(g["ln_w"]), T(g["ln_b"])), g["ln_y"], 1e-6)
+    close(R.gelu(T(g["gelu_x"]), False), g["gelu_erf"], 1e-7)
+    close(R.gelu(T(g["gelu_x"]), True), g["gelu_tanh"], 1e-7)
+    sd = synth.make_state_dict(ovcfg.preset("vit-tiny-patch16-160"), 0)
+    y = R.resblock(T(g["blk_x"]), sd, "visual.transformer.resblocks.0.", 3, False)
+    close(y, g["blk_y"], 2e-5)
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    cfg = ovcfg.preset("vit-tiny-patch16-160")
+    return cfg, synth.make_state_dict(cfg, 0)
+
+
+def test_tiny_tower_activations(tiny):
+    cfg, sd = tiny
+    g = golden("tiny16_160.npz")
+    img = T(g["images"])
+    x = R.patch_embed(img, sd, 16)
+    conv = torch.nn.functional.conv2d(img, sd["visual.conv1.weight"], None, stride=16)
+    close(conv, g["conv1"], 1e-5)
+    x = R.resblock(x, sd, "visual.transformer.resblocks.0.", 3, False)
+    close(x, g["block0"], 2e-5)
+    feat, tokens = R.vision_forward(img, sd, cfg["vision_cfg"], return_tokens=True)
+    close(tokens, g["block11"], 2e-4, 1e-4)
+    close(feat, g["image_features"], 1e-4, 1e-4)
+
+
+def test_tiny_text_and_forward(tiny):
+    cfg, sd = tiny
+    g = golden("tiny16_160.npz")
+    img, tok = T(g["images"]), T(g["tokens"])
+    close(R.encode_text(tok, sd, cfg), g["text_features"], 1e-4, 1e-4)
+    ni, nt, s = R.clip_forward(img, tok, sd, cfg)
+    close(ni, g["image_norm"], 2e-6)
+    close(nt, g["text_norm"], 2e-6)
+    close(s, g["logit_scale_exp"], 1e-5)
+    close(s * ni @ nt.T, g["logits_per_image"], 1e-4)
+    close(s * nt @ ni.T, g["logits_per_text"], 1e-4)
+    close(R.clip_loss(ni, nt, s), g["loss"], 1e-5)
+
+
+def test_tiny_testcat_zero_shot_table(tiny):
+    cfg, sd = tiny
+    g = golden("tiny16_160_testcat.npz")
+    img, tok = T(g["images"].astype(np.float32)), T(g["tokens"])
+    cos, probs, order = R.zero_shot_table(R.encode_image(img, sd, cfg), R.encode_text(tok, sd, cfg),
+                                          sd["logit_scale"])
+    close(cos, g["cosine"], 2e-6)
+    close(probs, g["probs"], 2e-5)
+    assert np.array_equal(order.numpy(), g["argsort"])            # top-k indices bit-exact
+    assert np.array_equal(probs.argmax(-1).numpy(), g["best"])
+
+
+@pytest.mark.timeout(600)
+def test_large_features():
+    cfg = ovcfg.preset("vit-large-patch14-224")
+    sd = synth.make_state_dict(cfg, 0)
+    g = golden("large14_224.npz")
+    img, tok = T(g["images"].astype(np.float32)), T(g["tokens"])
+    feat, tokens = R.vision_forward(img, sd, cfg["vision_cfg"], return_tokens=True)
+    close(tokens[:, :4], g["block23_head"], 1e-3, 1e-4)
+    close(tokens[:, -2:], g["block23_tail"], 1e-3, 1e-4)
+    close(feat, g["image_features"], 2e-4, 1e-4)
+    tf = R.encode_text(tok, sd, cfg)
+    close(tf, g["text_features"], 2e-4, 1e-4)
+    ni, nt = R.l2_normalize(feat), R.l2_normalize(tf)
+    close(R.clip_loss(ni, nt, sd["logit_scale"].exp()), g["loss"], 1e-5)
+    # the reference's own bf16 mode sits this far from its fp32 mode (documents the bf16 budget)
+    cb = torch.nn.functional.cosine_similarity(T(g["image_features_refbf16"]), T(g["image_features"]))
+    assert float((1 - cb).max()) < 1e-3
+
+
+@pytest.mark.timeout(600)
+def test_small8_384_features():
+    cfg = ovcfg.preset("vit-small-patch8-384")
+    sd = synth.make_state_dict(cfg, 0)
+    g = golden("small8_384.npz")
+    feat, tokens = R.vision_forward(T(g["images"].astype(np.float32)), sd, cfg["vision_cfg"], return_tokens=True)
+    close(tokens[:, :4], g["block11_head"], 5e-4, 1e-4)
+    close(feat, g["image_features"], 2e-4, 1e-4)
+
+
+def test_cliploss_local_losses_match_reference_ranks():
+    g = golden("cliploss_ws.npz")
+    img, txt, s = T(g["img"]), T(g["txt"]), T(g["scale"])
+    close(R.clip_loss(img, txt, s), g["loss_ws1"], 1e-6)
+    for ws in (2, 8):
+        b = img.shape[0] // ws
+        mine = [float(R.clip_loss(img[r * b:(r + 1) * b], txt[r * b:(r + 1) * b], s, img, txt, r)) for r in range(ws)]
+        np.testing.assert_allclose(mine, g[f"local_losses_ws{ws}"], atol=1e-6)
+        # mean over ranks of the local losses == the global single-process loss
+        assert abs(np.mean(mine) - float(g["loss_ws1"])) < 1e-6
