@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py — images/sec of the ViT-L/14@224 encode-and-contrast step on N x MI355X (BASELINE.json metric).
+
+One step = image tower + text tower (bf16 compute, fp32 accumulate) on a per-GPU batch of synthetic
+image/caption pairs already resident in HBM, the RCCL all-gather of the L2-normalised embeddings when
+N > 1, and the fused InfoNCE on the local [b, N*b] logit strips.  Pure data parallelism, weak scaling
+(per-GPU batch fixed).  Prints ONE JSON line on rank 0.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch                      # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0         # dense MFMA bf16, /opt/skills/guides/MI355X_MICROARCH.md (chip-level parameters)
+PROF_CLASSES = {"ln": 0, "gemm_qkv": 1, "attention": 2, "gemm_out": 3, "gemm_fc": 4, "gemm_proj": 5}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (images = captions)")
+    ap.add_argument("--model", default="vit-large-patch14-224")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
+    ap.add_argument("--breakdown", action="store_true", help="extra untimed step timing every kernel class")
+    return ap.parse_args()
+
+
+def host_cores() -> int:
+    """CPU threads this process may really use: affinity mask, capped by the cgroup CPU quota (the GPU box grants a
+    1-GPU job a 16-CPU share of a 256-thread host)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
+def cpu_baseline(cfg, sd, budget_s: float):
+    """The oracle (CPU restatement of the reference path, plain torch fp32 aten kernels) on a bounded sample of the
+    SAME workload: image+text towers + InfoNCE at batch 4, >= budget_s seconds of work after one warm-up."""
+    from openvision_amd import synth
+    from oracle import clip_ref as R
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    b = 4
+    img = synth.make_images(b, cfg["vision_cfg"]["image_size"], seed=123)
+    tok = synth.make_captions(b, cfg["text_cfg"]["context_length"], cfg["text_cfg"]["vocab_size"], seed=123)
+    sdf = {k: v.float() for k, v in sd.items()}
+
+    def step():
+        with torch.no_grad():
+            ni, nt, s = R.clip_forward(img, tok, sdf, cfg)
+            return R.clip_loss(ni, nt, s)
+    step()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        step()
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or n >= 50:
+            break
+    return {"value": round(n * b / dt, 3), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"{n} iterations of batch {b} (image+text towers + InfoNCE, fp32 torch CPU ops via oracle/clip_ref.py), "
+                      f"{dt:.1f} s after 1 warm-up"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        a.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)       # "nccl" IS RCCL on ROCm
+
+    from openvision_amd import preset, synth, _lib
+    from openvision_amd.model import create_model
+    from openvision_amd.loss import ClipLoss
+    lib = _lib.load()
+    _lib.check(lib.ov_device_check(), "ov_device_check")
+
+    cfg = preset(a.model)
+    sd = synth.make_state_dict(cfg, seed=0)
+    model = create_model(cfg, device=dev, state_dict=sd)
+    loss_fn = ClipLoss(local_loss=True, rank=rank, world_size=world)
+    b = a.batch
+    S = cfg["vision_cfg"]["image_size"]
+    T, V = cfg["text_cfg"]["context_length"], cfg["text_cfg"]["vocab_size"]
+    images = synth.make_images(b, S, seed=1000 + rank).to(dev).to(torch.bfloat16)      # resident in HBM
+    tokens = synth.make_captions(b, T, V, seed=1000 + rank).to(dev)
+
+    def step():
+        ni, nt, s = model(images, tokens)
+        return loss_fn(ni, nt, s)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        loss = step()
+    # in-situ timing of the dominant kernel (the vision MLP c_fc GEMM) during the timed region
+    nrec = a.steps * (cfg["vision_cfg"]["layers"] + cfg["text_cfg"]["layers"]) + 8
+    _lib.check(lib.ov_profile_enable(1 << PROF_CLASSES["gemm_fc"], nrec), "ov_profile_enable")
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    tot, cnt = C.c_double(0), C.c_int(0)
+    _lib.check(lib.ov_profile_read(PROF_CLASSES["gemm_fc"], C.byref(tot), C.byref(cnt)), "ov_profile_read")
+    _lib.check(lib.ov_profile_enable(0, 0), "ov_profile_enable")
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    model.check_token_range()
+    loss_val = float(loss)
+
+    # per-class breakdown (diagnostic, untimed)
+    breakdown = None
+    if a.breakdown and rank == 0:
+        _lib.check(lib.ov_profile_enable(0x3f, 8 * (cfg["vision_cfg"]["layers"] + cfg["text_cfg"]["layers"]) + 8), "prof")
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); step(); e1.record()
+        torch.cuda.synchronize()
+        breakdown = {"step_ms": round(e0.elapsed_time(e1), 3)}
+        for name, cid in PROF_CLASSES.items():
+            t_, c_ = C.c_double(0), C.c_int(0)
+            _lib.check(lib.ov_profile_read(cid, C.byref(t_), C.byref(c_)), "prof read")
+            breakdown[name] = {"ms": round(t_.value, 3), "launches": c_.value}
+        _lib.check(lib.ov_profile_enable(0, 0), "prof off")
+
+    if rank == 0:
+        flops = synth.model_flops(cfg)
+        vl, tl = cfg["vision_cfg"]["layers"], cfg["text_cfg"]["layers"]
+        # dominant kernel: gemm_bf16_256x256<GELU> (c_fc).  Algorithmic FLOP per launch = 2*M*N*K.
+        g = S // cfg["vision_cfg"]["patch_size"]
+        Lv, Dv, Dt = g * g + 1, cfg["vision_cfg"]["width"], cfg["text_cfg"]["width"]
+        fc_v = 2.0 * b * Lv * Dv * int(Dv * cfg["vision_cfg"]["mlp_ratio"])
+        fc_t = 2.0 * b * T * Dt * int(Dt * cfg["text_cfg"].get("mlp_ratio", 4.0))
+        launches = max(cnt.value, 1)
+        flop_per_launch = (fc_v * vl + fc_t * tl) / (vl + tl)
+        avg_ms = tot.value / launches
+        achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get("gemm_fc_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "images/sec (node) ViT-L/14@224 fwd+InfoNCE",
+            "value": round(world * b * a.steps / dt, 2),
+            "unit": "images/sec",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{a.model}: image tower + text tower (T={T}) + InfoNCE, per-GPU batch {b}, "
+                                   f"formula weights, bf16 MFMA / fp32 accumulate",
+                       "global_batch": world * b, "parallelism": f"dp{world}",
+                       "gflop_per_pair": round(flops["pair"] / 1e9, 2),
+                       "model_tflops_per_gpu": round(flops["pair"] * b * a.steps / dt / 1e12, 1)},
+            "loss": round(loss_val, 5),
+            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_256x256<bias+GELU> (mlp.c_fc, vision+text towers)",
+                         "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                         "avg_launch_ms": round(avg_ms, 4), "launches": cnt.value,
+                         "flop_per_launch": flop_per_launch},
+        }
+        if breakdown:
+            out["breakdown"] = breakdown
+        if world == 1 and a.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(cfg, sd, a.cpu_seconds)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,224 @@
+/* ovhip.h — C ABI of libovhip.so: the MI355X (gfx950) encode-and-contrast path of OpenVision.
+ *
+ * Drop-in boundary.  The reference has no FFI layer: its "operator API" for this path
+ * is the Python surface of open_clip.model.CLIP / open_clip.loss.ClipLoss, whose arithmetic is
+ * delegated to torch aten kernels.  Each entry point below replaces the aten work behind one piece of
+ * that surface (reference paths relative to /root/reference/src/convert_upload/open_clip/):
+ *
+ *   ov_layernorm        LayerNorm / LayerNormFp32.forward                     transformer.py:15-30
+ *   ov_gemm             nn.Linear (c_fc/c_proj/out_proj/in_proj), `@ proj`    transformer.py:225,232-236,645-646
+ *   ov_attention        nn.MultiheadAttention core (softmax(qk^T/sqrt(hd)) v) transformer.py:239-252
+ *   ov_im2col_patches   conv1 (stride = kernel = P) operand gather            transformer.py:469,610-612
+ *   ov_cls_rows         class_embedding concat + pos-emb row 0                transformer.py:615-617
+ *   ov_mean_pool        _global_pool 'avg' / 'tok'                            transformer.py:599-603
+ *   ov_text_embed       token_embedding(text) + positional_embedding         model.py:272-274
+ *   ov_gather_rows      text_global_pool 'last' / 'first'                     transformer.py:655-658
+ *   ov_l2norm           F.normalize(x, dim=-1)                                model.py:267,284
+ *   ov_logits           CLIP.get_logits (scale * img @ txt^T)                 model.py:286-293
+ *   ov_clip_loss        ClipLoss.get_logits + cross_entropy both ways         loss.py:102-131
+ *   ov_tower_*          Transformer.forward (the resblock loop)               transformer.py:355-366, 254-265
+ *   ov_vision_* / ov_text_*   VisionTransformer.forward / CLIP.encode_text    transformer.py:609-651, model.py:269-284
+ *
+ * Conventions: plain pointers and sizes only (no torch types).  All pointers are DEVICE pointers owned
+ * by the caller unless stated; every call enqueues on `stream` (a hipStream_t passed as void*) and
+ * returns without synchronising.  Return value: 0 = OK, negative = error (see ov_error_string); nothing
+ * throws across the boundary.  No call allocates device memory: workspaces are sized by
+ * ov_*_workspace_bytes and provided by the caller.  Activations are bf16 row-major; LN affine params,
+ * biases and final embeddings are fp32 (the reference's bf16 mode keeps LN in fp32: model.py:143).
+ */
+#ifndef OVHIP_H
+#define OVHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OV_ABI_VERSION 1
+
+typedef void* ov_stream_t;            /* hipStream_t */
+typedef uint16_t ov_bf16;             /* raw bfloat16 bits */
+
+enum ov_status {
+    OV_OK = 0,
+    OV_ERR_INVALID = -1,              /* bad argument (null pointer, size, alignment) */
+    OV_ERR_UNSUPPORTED = -2,          /* shape outside what the kernels cover */
+    OV_ERR_WORKSPACE = -3,            /* workspace too small */
+    OV_ERR_NO_DEVICE = -4,            /* no gfx950 device visible */
+    OV_ERR_HIP = -1000                /* -(1000 + hipError_t) */
+};
+
+enum ov_dtype { OV_F32 = 0, OV_BF16 = 1 };
+
+enum ov_epilogue {
+    OV_EPI_BIAS = 0,                  /* C = bf16(acc + bias)                (bias may be NULL) */
+    OV_EPI_BIAS_GELU_ERF = 1,         /* C = bf16(gelu_erf(acc + bias))      vision MLP, vit.py:202 */
+    OV_EPI_BIAS_GELU_TANH = 2,        /* C = bf16(gelu_tanh(acc + bias))     text MLP, text_transformer.py:117 */
+    OV_EPI_BIAS_RESIDUAL = 3          /* C = bf16(bf16(acc + bias) + R)      x = x + f(x), transformer.py:263-264 */
+};
+
+int         ov_abi_version(void);
+const char* ov_error_string(int status);
+/* 0 if a gfx950 device is usable by this process, else OV_ERR_NO_DEVICE / OV_ERR_HIP-x. */
+int         ov_device_check(void);
+
+/* ---- granular operators ------------------------------------------------------------------------ */
+
+/* y[r,:] = (x[r,:] - mean) * rsqrt(var + eps) * gamma + beta ; fp32 statistics (biased variance).
+ * x_dtype/y_dtype: OV_BF16 or OV_F32.  D % 8 == 0, D <= 8192.  ldx/ldy in elements. */
+int ov_layernorm(const void* x, int x_dtype, int64_t ldx, const float* gamma, const float* beta,
+                 void* y, int y_dtype, int64_t ldy, int64_t rows, int D, float eps, ov_stream_t stream);
+
+/* C[M,N] = epilogue(A[M,K] * W[N,K]^T + bias[N]).  A, W, C, R bf16 row-major; bias fp32 or NULL.
+ * K % 64 == 0; lda, ldw, ldc, ldr % 8 == 0; N % 8 == 0.
+ * Row remapping for the patch-embed use (0 = identity):
+ *   out_group  > 0 : output row = m + m / out_group + 1      (skip one cls row per image)
+ *   resid_mod  > 0 : residual row = (m % resid_mod) + resid_off   (pos-emb table broadcast over batch)
+ * C may alias R when the row maps are identities (in-place residual add). */
+int ov_gemm(const ov_bf16* A, int64_t lda, const ov_bf16* W, int64_t ldw, const float* bias,
+            ov_bf16* C, int64_t ldc, int64_t M, int N, int K, int epilogue,
+            const ov_bf16* R, int64_t ldr, int out_group, int resid_mod, int resid_off,
+            ov_stream_t stream);
+
+/* Non-causal, unmasked multi-head self-attention on a packed qkv activation.
+ * qkv: [B*L, 3*H*hd] bf16 (q | k | v column blocks, heads contiguous inside each, ld = ld_qkv);
+ * out: [B*L, H*hd] bf16 (heads merged, ld = ld_out).  scale multiplies q.k (hd^-0.5).  hd == 64. */
+int ov_attention(const ov_bf16* qkv, int64_t ld_qkv, ov_bf16* out, int64_t ld_out,
+                 int B, int L, int H, int hd, float scale, ov_stream_t stream);
+
+/* Patch gather for conv1: image [B,3,S,S] (img_dtype) -> P[B*g*g, Kpad] bf16,
+ * column index c*P*P + i*P + j (the flattening of conv1.weight[D,3,P,P]); columns >= 3*P*P zeroed. */
+int ov_im2col_patches(const void* image, int img_dtype, ov_bf16* out, int B, int S, int P, int Kpad,
+                      ov_stream_t stream);
+
+/* x[b*L + 0, :] = bf16(bf16(cls[:]) + bf16(pos[0,:]))  for every image b. cls/pos fp32. */
+int ov_cls_rows(ov_bf16* x, int64_t ldx, const float* cls, const float* pos0, int B, int L, int D,
+                ov_stream_t stream);
+
+/* out[b,:] = mean over tokens first..L-1 of x[b*L + t, :]  (first = 1: skip cls; 'avg' pooling). fp32 out. */
+int ov_mean_pool(const ov_bf16* x, int64_t ldx, float* out, int B, int L, int D, int first,
+                 ov_stream_t stream);
+
+/* x[b*T + t, :] = bf16(bf16(table[tokens[b,t], :]) + bf16(pos[t, :])).  tokens int64; table/pos bf16.
+ * Token ids outside [0, V) set *err_flag (device int, may be NULL) and are clamped. */
+int ov_text_embed(const int64_t* tokens, const ov_bf16* table, const ov_bf16* pos, ov_bf16* x,
+                  int64_t ldx, int B, int T, int D, int V, int* err_flag, ov_stream_t stream);
+
+/* out[b, :] = x[b*L + t, :] (row gather; t = L-1 for text 'last' pooling). bf16 -> bf16. */
+int ov_gather_rows(const ov_bf16* x, int64_t ldx, ov_bf16* out, int64_t ldo, int B, int L, int t, int D,
+                   ov_stream_t stream);
+
+/* bf16 <-> fp32 row conversion helpers (strided rows). */
+int ov_convert(const void* src, int src_dtype, int64_t lds, void* dst, int dst_dtype, int64_t ldd,
+               int64_t rows, int cols, ov_stream_t stream);
+
+/* y[r,:] = x[r,:] / max(||x[r,:]||_2, 1e-12)   (F.normalize).  x bf16 or fp32, y fp32. */
+int ov_l2norm(const void* x, int x_dtype, int64_t ldx, float* y, int64_t ldy, int64_t rows, int E,
+              ov_stream_t stream);
+
+/* out[i, j] = scale * <X[i,:], Y[j,:]>  fp32 in/out (CLIP.get_logits: model.py:286-293).  E % 8 == 0. */
+int ov_logits(const float* X, const float* Y, float* out, int64_t ldo, int n1, int n2, int E, float scale,
+              ov_stream_t stream);
+
+/* Local-strip InfoNCE (ClipLoss with local_loss semantics; world_size 1 = plain ClipLoss).
+ *   img, txt      : this rank's L2-normalised embeddings [b, E] fp32
+ *   all_img/all_txt: gathered embeddings [N, E] fp32 in rank order (== img/txt when N == b)
+ *   labels are i + label_offset (label_offset = b * rank, loss.py:93-94)
+ *   loss_out[0] = (CE(scale*img@all_txt^T) + CE(scale*txt@all_img^T)) / 2      (fp32, device)
+ *   lse_out (optional, may be NULL): [4, b] fp32 = lse_img, diag_img, lse_txt, diag_txt
+ * workspace: ov_clip_loss_workspace_bytes(b, N) bytes. Logits are never materialised. */
+size_t ov_clip_loss_workspace_bytes(int b, int N);
+int ov_clip_loss(const float* img, const float* txt, const float* all_img, const float* all_txt,
+                 int b, int N, int E, float logit_scale, int label_offset, float* loss_out,
+                 float* lse_out, void* workspace, size_t workspace_bytes, ov_stream_t stream);
+
+/* ---- in-situ kernel timing (used by bench.py for the roofline object; off by default) ------------------
+ * ov_profile_enable(mask, n): bracket every launch of the selected classes inside ov_tower_forward with a pair
+ * of HIP events recorded on the launch stream (n = max launches recorded; resets earlier records; mask 0 = off).
+ * ov_profile_read(cls, &ms, &count): synchronises the recorded events and returns the summed device time. */
+enum ov_profile_class {
+    OV_PROF_LN = 0, OV_PROF_GEMM_QKV = 1, OV_PROF_ATTN = 2, OV_PROF_GEMM_OUT = 3, OV_PROF_GEMM_FC = 4, OV_PROF_GEMM_PROJ = 5
+};
+int ov_profile_enable(unsigned class_mask, int max_records);
+int ov_profile_read(int cls, double* total_ms, int* count);
+
+/* ---- tower level (the resblock loop and the two encoders) --------------------------------------- */
+
+typedef struct ov_tower ov_tower;     /* opaque host object holding BORROWED device weight pointers */
+
+typedef struct {
+    int width;        /* D */
+    int layers;
+    int heads;
+    int mlp;          /* true hidden width (int(D*mlp_ratio)) */
+    int mlp_pad;      /* leading dimension / padded hidden width, % 64 == 0, >= mlp */
+    int gelu_tanh;    /* 0 = erf (vision), 1 = tanh (text) */
+    float ln_eps;     /* 1e-6 */
+} ov_tower_cfg;
+
+typedef struct {      /* one ResidualAttentionBlock; weights bf16 [out,in] row-major, LN/bias fp32 */
+    const float *ln1_w, *ln1_b;
+    const ov_bf16* qkv_w;  const float* qkv_b;     /* [3D, D], [3D]   attn.in_proj_*        */
+    const ov_bf16* out_w;  const float* out_b;     /* [D, D],  [D]    attn.out_proj.*       */
+    const float *ln2_w, *ln2_b;
+    const ov_bf16* fc_w;   const float* fc_b;      /* [mlp_pad, D], [mlp_pad] (pad rows = 0) */
+    const ov_bf16* proj_w; const float* proj_b;    /* [D, mlp_pad] (pad cols = 0), [D]      */
+} ov_block_weights;
+
+ov_tower* ov_tower_create(const ov_tower_cfg* cfg);
+void      ov_tower_destroy(ov_tower* t);
+int       ov_tower_set_block(ov_tower* t, int layer, const ov_block_weights* w);
+size_t    ov_tower_workspace_bytes(const ov_tower* t, int B, int L);
+/* x[B*L, D] bf16 is updated in place through all `layers` blocks. */
+int       ov_tower_forward(const ov_tower* t, ov_bf16* x, int B, int L, void* workspace,
+                           size_t workspace_bytes, ov_stream_t stream);
+
+typedef struct {      /* VisionTransformer front/back ends (OpenVision: no ln_pre, no conv bias) */
+    int image_size, patch_size, kpad;              /* kpad = roundup(3*P*P, 64) */
+    int pool_avg;                                  /* 1 = 'avg' (skip cls), 0 = 'tok' */
+    int final_ln_after_pool;                       /* 1 for OpenVision */
+    int embed_dim, embed_pad;                      /* E, roundup(E, 8) */
+    const ov_bf16* conv_w;                         /* [D, kpad] bf16, pad cols = 0 */
+    const float* cls;                              /* [D] */
+    const ov_bf16* pos;                            /* [L, D] bf16 */
+    const float* pos_f32;                          /* [L, D] fp32 (row 0 used for the cls row) */
+    const float *ln_post_w, *ln_post_b;            /* [D] */
+    const ov_bf16* proj_t;                         /* [E, D] bf16 = visual.proj^T */
+} ov_vision_head;
+
+size_t ov_vision_workspace_bytes(const ov_tower* t, const ov_vision_head* h, int B);
+/* image [B,3,S,S] -> tokens x[B*L, D] bf16 (patch embed + cls + pos); x caller-provided. */
+int ov_vision_embed(const ov_tower* t, const ov_vision_head* h, const void* image, int img_dtype, int B,
+                    ov_bf16* x, void* workspace, size_t workspace_bytes, ov_stream_t stream);
+/* tokens x[B*L, D] -> features [B, E] fp32 (pool -> ln_post -> proj), optionally L2-normalised. */
+int ov_vision_head_forward(const ov_tower* t, const ov_vision_head* h, const ov_bf16* x, int B,
+                           float* features, int normalize, void* workspace, size_t workspace_bytes,
+                           ov_stream_t stream);
+/* VisionTransformer.forward + optional F.normalize: image -> [B, E] fp32. */
+int ov_encode_image(const ov_tower* t, const ov_vision_head* h, const void* image, int img_dtype, int B,
+                    float* features, int normalize, void* workspace, size_t workspace_bytes,
+                    ov_stream_t stream);
+
+typedef struct {      /* CLIP text front/back ends */
+    int context_length, vocab_size;
+    int pool_last;                                 /* 1 = 'last', 0 = 'first' */
+    int embed_dim;
+    const ov_bf16* token_embedding;                /* [V, D] bf16 */
+    const ov_bf16* pos;                            /* [T, D] bf16 */
+    const float *ln_final_w, *ln_final_b;          /* [D] */
+    const ov_bf16* proj_t;                         /* [E, D] bf16 = text_projection^T */
+} ov_text_head;
+
+size_t ov_text_workspace_bytes(const ov_tower* t, const ov_text_head* h, int B);
+/* CLIP.encode_text: tokens int64 [B, T] -> [B, E] fp32.  *err_flag (device int, may be NULL) is set
+ * to 1 when a token id is outside [0, V). */
+int ov_encode_text(const ov_tower* t, const ov_text_head* h, const int64_t* tokens, int B,
+                   float* features, int normalize, int* err_flag, void* workspace,
+                   size_t workspace_bytes, ov_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OVHIP_H */

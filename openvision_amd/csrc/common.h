@@ -1,0 +1,59 @@
+// common.h — shared device helpers for the gfx950 kernels (wave64, bf16 bit tricks, vector types).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/ovhip.h"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+
+#define OV_WAVE 64
+
+#define OV_LAUNCH_CHECK()                                            \
+    do {                                                             \
+        hipError_t e__ = hipGetLastError();                          \
+        if (e__ != hipSuccess) return OV_ERR_HIP - (int)e__;         \
+    } while (0)
+
+static inline int ov_hip(hipError_t e) { return e == hipSuccess ? OV_OK : OV_ERR_HIP - (int)e; }
+
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short h) {
+    return __uint_as_float(((unsigned int)h) << 16);
+}
+__device__ __forceinline__ float bf16lo_to_f32(unsigned int w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16hi_to_f32(unsigned int w) { return __uint_as_float(w & 0xffff0000u); }
+
+// round-to-nearest-even f32 -> bf16 (plain cast: hipcc emits v_cvt_pk_bf16_f32 on gfx950, NaN-safe)
+__device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    bf16x2_t v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned int, v);
+}
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float x) {
+    __bf16 b = (__bf16)x;
+    return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ float round_bf16(float x) { return bf16_bits_to_f32(f32_to_bf16_bits(x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+    // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))  == x * sigmoid(2u)
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    return x / (1.0f + __expf(-2.0f * u));
+}

@@ -1,0 +1,126 @@
+// layernorm.hip — row LayerNorm with fp32 statistics (HBM-bound), gfx950.
+//
+// Replaces aten::native_layer_norm behind LayerNorm / LayerNormFp32.forward
+// (reference open_clip/transformer.py:15-30; eps = 1e-6 from transformer.py:458,491,499,537,690,720).
+// One 64-lane wave per row: each lane keeps its 16-byte chunks of the row in registers, so the row is
+// read from HBM exactly once; mean and (biased) variance are two wave reductions over registers
+// (two-pass, no E[x^2]-E[x]^2 cancellation); output is written once as 16-byte stores.
+// Algorithmic traffic: rows * D * (sizeof(in) + sizeof(out)) bytes (+ gamma/beta, L2-resident).
+#include "common.h"
+
+namespace {
+
+template <int NCH, bool IN_F32, bool OUT_F32>
+__global__ __launch_bounds__(256) void layernorm_rows(const void* __restrict__ xv, int64_t ldx,
+                                                      const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, void* __restrict__ yv,
+                                                      int64_t ldy, int64_t rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int nchunk = D >> 3;
+    const float invD = 1.0f / (float)D;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        float v[NCH][8];
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int ch = lane + c * 64;
+            if (ch < nchunk) {
+                if (IN_F32) {
+                    const float4* p = (const float4*)((const float*)xv + row * ldx + ch * 8);
+                    const float4 a = p[0], b = p[1];
+                    v[c][0] = a.x; v[c][1] = a.y; v[c][2] = a.z; v[c][3] = a.w;
+                    v[c][4] = b.x; v[c][5] = b.y; v[c][6] = b.z; v[c][7] = b.w;
+                } else {
+                    const u32x4_t w = *(const u32x4_t*)((const ov_bf16*)xv + row * ldx + ch * 8);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[c][2 * e] = bf16lo_to_f32(w[e]);
+                        v[c][2 * e + 1] = bf16hi_to_f32(w[e]);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += v[c][e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[c][e] = 0.f;
+            }
+        }
+        const float mean = wave_sum(s) * invD;
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            if (lane + c * 64 < nchunk) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float d = v[c][e] - mean;
+                    q += d * d;
+                }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(q) * invD + eps);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int ch = lane + c * 64;
+            if (ch < nchunk) {
+                const float4 g0 = *(const float4*)(gamma + ch * 8), g1 = *(const float4*)(gamma + ch * 8 + 4);
+                const float4 b0 = *(const float4*)(beta + ch * 8), b1 = *(const float4*)(beta + ch * 8 + 4);
+                float o[8];
+                o[0] = (v[c][0] - mean) * rstd * g0.x + b0.x;
+                o[1] = (v[c][1] - mean) * rstd * g0.y + b0.y;
+                o[2] = (v[c][2] - mean) * rstd * g0.z + b0.z;
+                o[3] = (v[c][3] - mean) * rstd * g0.w + b0.w;
+                o[4] = (v[c][4] - mean) * rstd * g1.x + b1.x;
+                o[5] = (v[c][5] - mean) * rstd * g1.y + b1.y;
+                o[6] = (v[c][6] - mean) * rstd * g1.z + b1.z;
+                o[7] = (v[c][7] - mean) * rstd * g1.w + b1.w;
+                if (OUT_F32) {
+                    float4* p = (float4*)((float*)yv + row * ldy + ch * 8);
+                    p[0] = make_float4(o[0], o[1], o[2], o[3]);
+                    p[1] = make_float4(o[4], o[5], o[6], o[7]);
+                } else {
+                    u32x4_t w = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]),
+                                 pack_bf16x2(o[6], o[7])};
+                    *(u32x4_t*)((ov_bf16*)yv + row * ldy + ch * 8) = w;
+                }
+            }
+        }
+    }
+}
+
+template <int NCH>
+int launch_ln(const void* x, int xd, int64_t ldx, const float* g, const float* b, void* y, int yd, int64_t ldy,
+              int64_t rows, int D, float eps, hipStream_t st) {
+    int64_t blocks = (rows + 3) / 4;
+    if (blocks > 16384) blocks = 16384;
+    dim3 grid((unsigned)blocks), blk(256);
+    if (xd == OV_BF16 && yd == OV_BF16)
+        hipLaunchKernelGGL((layernorm_rows<NCH, false, false>), grid, blk, 0, st, x, ldx, g, b, y, ldy, rows, D, eps);
+    else if (xd == OV_BF16 && yd == OV_F32)
+        hipLaunchKernelGGL((layernorm_rows<NCH, false, true>), grid, blk, 0, st, x, ldx, g, b, y, ldy, rows, D, eps);
+    else if (xd == OV_F32 && yd == OV_BF16)
+        hipLaunchKernelGGL((layernorm_rows<NCH, true, false>), grid, blk, 0, st, x, ldx, g, b, y, ldy, rows, D, eps);
+    else
+        hipLaunchKernelGGL((layernorm_rows<NCH, true, true>), grid, blk, 0, st, x, ldx, g, b, y, ldy, rows, D, eps);
+    OV_LAUNCH_CHECK();
+    return OV_OK;
+}
+
+}  // namespace
+
+extern "C" int ov_layernorm(const void* x, int x_dtype, int64_t ldx, const float* gamma, const float* beta,
+                            void* y, int y_dtype, int64_t ldy, int64_t rows, int D, float eps,
+                            ov_stream_t stream) {
+    if (!x || !y || !gamma || !beta || rows <= 0 || D <= 0) return OV_ERR_INVALID;
+    if ((x_dtype != OV_BF16 && x_dtype != OV_F32) || (y_dtype != OV_BF16 && y_dtype != OV_F32)) return OV_ERR_INVALID;
+    if (D % 8 || D > 8192 || ldx % 8 || ldy % 8 || ldx < D || ldy < D) return OV_ERR_UNSUPPORTED;
+    if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15) return OV_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    const int nch = (D / 8 + 63) / 64;
+    if (nch <= 1) return launch_ln<1>(x, x_dtype, ldx, gamma, beta, y, y_dtype, ldy, rows, D, eps, st);
+    if (nch <= 2) return launch_ln<2>(x, x_dtype, ldx, gamma, beta, y, y_dtype, ldy, rows, D, eps, st);
+    if (nch <= 3) return launch_ln<3>(x, x_dtype, ldx, gamma, beta, y, y_dtype, ldy, rows, D, eps, st);
+    if (nch <= 4) return launch_ln<4>(x, x_dtype, ldx, gamma, beta, y, y_dtype, ldy, rows, D, eps, st);
+    if (nch <= 8) return launch_ln<8>(x, x_dtype, ldx, gamma, beta, y, y_dtype, ldy, rows, D, eps, st);
+    return launch_ln<16>(x, x_dtype, ldx, gamma, beta, y, y_dtype, ldy, rows, D, eps, st);
+}

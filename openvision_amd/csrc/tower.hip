@@ -1,0 +1,316 @@
+// tower.hip — host-side launch sequences: the resblock loop and the two encoders (no device code here).
+//
+//   ov_tower_forward        Transformer.forward / ResidualAttentionBlock.forward   open_clip/transformer.py:355-366, 254-265
+//   ov_vision_embed         conv1 + cls + pos-emb (ln_pre = Identity)              transformer.py:610-620
+//   ov_vision_head_forward  _global_pool -> ln_post -> @ proj (-> F.normalize)     transformer.py:638-646, model.py:267
+//   ov_encode_image         VisionTransformer.forward                              transformer.py:609-651
+//   ov_encode_text          CLIP.encode_text                                       model.py:269-284
+//
+// Per block, seven launches on the caller's stream (all asynchronous, nothing allocated):
+//   LN1 -> QKV GEMM(+bias) -> attention -> out-proj GEMM(+bias +residual, in place)
+//   LN2 -> FC GEMM(+bias +GELU) -> proj GEMM(+bias +residual, in place)
+// Workspace per tower call: h [M, D] | big [M, max(3D, mlp_pad)]  (qkv and the MLP hidden alias).
+#include "common.h"
+#include <new>
+#include <vector>
+#include <mutex>
+
+struct ov_tower {
+    ov_tower_cfg cfg;
+    ov_block_weights* blocks;
+    unsigned char* set;
+};
+
+namespace {
+// ---- optional in-situ kernel timing (HIP events on the caller's stream; off by default) -----------------
+struct ProfRec { int cls; hipEvent_t e0, e1; };
+struct Profiler {
+    std::mutex mu;
+    unsigned mask = 0;
+    std::vector<hipEvent_t> pool;      // unused events
+    std::vector<ProfRec> recs;
+} g_prof;
+
+struct ProfScope {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipStream_t st;
+    int cls;
+    bool on = false;
+    ProfScope(int c, ov_stream_t s) : st((hipStream_t)s), cls(c) {
+        if (!(g_prof.mask & (1u << c))) return;
+        std::lock_guard<std::mutex> lk(g_prof.mu);
+        if (g_prof.pool.size() < 2) return;
+        e0 = g_prof.pool.back(); g_prof.pool.pop_back();
+        e1 = g_prof.pool.back(); g_prof.pool.pop_back();
+        on = true;
+        (void)hipEventRecord(e0, st);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(e1, st);
+        std::lock_guard<std::mutex> lk(g_prof.mu);
+        g_prof.recs.push_back({cls, e0, e1});
+    }
+};
+#define OV_PROF(cls, call) [&]() { ProfScope ps__(cls, stream); return (call); }()
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+inline int max_i(int a, int b) { return a > b ? a : b; }
+
+struct VisionWs { size_t x, tower, pooled, lnrow, feat, total; };
+inline VisionWs vision_ws(const ov_tower* t, const ov_vision_head* h, int B) {
+    const int g = h->image_size / h->patch_size, L = g * g + 1, D = t->cfg.width;
+    VisionWs w;
+    size_t off = 0;
+    w.x = off;      off += align_up((size_t)B * L * D * 2, 256);
+    w.tower = off;  off += align_up(ov_tower_workspace_bytes(t, B, L), 256);
+    w.pooled = off; off += align_up((size_t)B * D * 4, 256);
+    w.lnrow = off;  off += align_up((size_t)B * D * 2, 256);
+    w.feat = off;   off += align_up((size_t)B * h->embed_pad * 2, 256);
+    w.total = off;
+    return w;
+}
+struct TextWs { size_t x, tower, last, lnrow, feat, total; };
+inline TextWs text_ws(const ov_tower* t, const ov_text_head* h, int B) {
+    const int T = h->context_length, D = t->cfg.width;
+    const int epad = (h->embed_dim + 7) / 8 * 8;
+    TextWs w;
+    size_t off = 0;
+    w.x = off;     off += align_up((size_t)B * T * D * 2, 256);
+    w.tower = off; off += align_up(ov_tower_workspace_bytes(t, B, T), 256);
+    w.last = off;  off += align_up((size_t)B * D * 2, 256);
+    w.lnrow = off; off += align_up((size_t)B * D * 2, 256);
+    w.feat = off;  off += align_up((size_t)B * epad * 2, 256);
+    w.total = off;
+    return w;
+}
+}  // namespace
+
+extern "C" int ov_abi_version(void) { return OV_ABI_VERSION; }
+
+extern "C" const char* ov_error_string(int status) {
+    switch (status) {
+        case OV_OK: return "ok";
+        case OV_ERR_INVALID: return "invalid argument";
+        case OV_ERR_UNSUPPORTED: return "shape/dtype not supported by the gfx950 kernels";
+        case OV_ERR_WORKSPACE: return "workspace too small";
+        case OV_ERR_NO_DEVICE: return "no gfx950 (MI355X) device visible";
+        default: break;
+    }
+    if (status <= OV_ERR_HIP) return hipGetErrorString((hipError_t)(OV_ERR_HIP - status));
+    return "unknown error";
+}
+
+extern "C" int ov_device_check(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return OV_ERR_HIP - (int)e;
+    if (n <= 0) return OV_ERR_NO_DEVICE;
+    int dev = 0;
+    e = hipGetDevice(&dev);
+    if (e != hipSuccess) return OV_ERR_HIP - (int)e;
+    hipDeviceProp_t p;
+    e = hipGetDeviceProperties(&p, dev);
+    if (e != hipSuccess) return OV_ERR_HIP - (int)e;
+    const char* arch = p.gcnArchName;
+    if (!(arch[0] == 'g' && arch[1] == 'f' && arch[2] == 'x' && arch[3] == '9' && arch[4] == '5' && arch[5] == '0'))
+        return OV_ERR_NO_DEVICE;
+    return OV_OK;
+}
+
+extern "C" int ov_profile_enable(unsigned class_mask, int max_records) {
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    for (auto& r : g_prof.recs) { g_prof.pool.push_back(r.e0); g_prof.pool.push_back(r.e1); }
+    g_prof.recs.clear();
+    g_prof.mask = class_mask;
+    if (max_records < 0) return OV_ERR_INVALID;
+    while ((int)g_prof.pool.size() < 2 * max_records) {
+        hipEvent_t e;
+        hipError_t err = hipEventCreate(&e);
+        if (err != hipSuccess) return OV_ERR_HIP - (int)err;
+        g_prof.pool.push_back(e);
+    }
+    return OV_OK;
+}
+
+extern "C" int ov_profile_read(int cls, double* total_ms, int* count) {
+    if (!total_ms || !count) return OV_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    double tot = 0.0;
+    int n = 0;
+    for (auto& r : g_prof.recs) {
+        if (r.cls != cls) continue;
+        hipError_t err = hipEventSynchronize(r.e1);
+        if (err != hipSuccess) return OV_ERR_HIP - (int)err;
+        float ms = 0.f;
+        err = hipEventElapsedTime(&ms, r.e0, r.e1);
+        if (err != hipSuccess) return OV_ERR_HIP - (int)err;
+        tot += ms;
+        ++n;
+    }
+    *total_ms = tot;
+    *count = n;
+    return OV_OK;
+}
+
+extern "C" ov_tower* ov_tower_create(const ov_tower_cfg* cfg) {
+    if (!cfg || cfg->width <= 0 || cfg->layers <= 0 || cfg->heads <= 0 || cfg->mlp <= 0) return nullptr;
+    if (cfg->width % cfg->heads || cfg->width % 64 || cfg->mlp_pad % 64 || cfg->mlp_pad < cfg->mlp) return nullptr;
+    ov_tower* t = new (std::nothrow) ov_tower;
+    if (!t) return nullptr;
+    t->cfg = *cfg;
+    t->blocks = new (std::nothrow) ov_block_weights[cfg->layers]();
+    t->set = new (std::nothrow) unsigned char[cfg->layers]();
+    if (!t->blocks || !t->set) { ov_tower_destroy(t); return nullptr; }
+    return t;
+}
+
+extern "C" void ov_tower_destroy(ov_tower* t) {
+    if (!t) return;
+    delete[] t->blocks;
+    delete[] t->set;
+    delete t;
+}
+
+extern "C" int ov_tower_set_block(ov_tower* t, int layer, const ov_block_weights* w) {
+    if (!t || !w || layer < 0 || layer >= t->cfg.layers) return OV_ERR_INVALID;
+    const void* p[] = {w->ln1_w, w->ln1_b, w->qkv_w, w->qkv_b, w->out_w, w->out_b, w->ln2_w, w->ln2_b,
+                       w->fc_w, w->fc_b, w->proj_w, w->proj_b};
+    for (const void* q : p)
+        if (!q || ((uintptr_t)q & 15)) return OV_ERR_INVALID;
+    t->blocks[layer] = *w;
+    t->set[layer] = 1;
+    return OV_OK;
+}
+
+extern "C" size_t ov_tower_workspace_bytes(const ov_tower* t, int B, int L) {
+    if (!t || B <= 0 || L <= 0) return 0;
+    const size_t M = (size_t)B * L;
+    const int D = t->cfg.width;
+    return align_up(M * D * 2, 256) + align_up(M * (size_t)max_i(3 * D, t->cfg.mlp_pad) * 2, 256);
+}
+
+extern "C" int ov_tower_forward(const ov_tower* t, ov_bf16* x, int B, int L, void* workspace, size_t workspace_bytes,
+                                ov_stream_t stream) {
+    if (!t || !x || !workspace || B <= 0 || L <= 0) return OV_ERR_INVALID;
+    if (workspace_bytes < ov_tower_workspace_bytes(t, B, L)) return OV_ERR_WORKSPACE;
+    if (((uintptr_t)x | (uintptr_t)workspace) & 15) return OV_ERR_INVALID;
+    const ov_tower_cfg& c = t->cfg;
+    const int D = c.width, H = c.heads, hd = D / H;
+    const int64_t M = (int64_t)B * L;
+    ov_bf16* h = (ov_bf16*)workspace;
+    ov_bf16* big = (ov_bf16*)((char*)workspace + align_up((size_t)M * D * 2, 256));
+    const float scale = 1.0f / sqrtf((float)hd);
+    const int gelu = c.gelu_tanh ? OV_EPI_BIAS_GELU_TANH : OV_EPI_BIAS_GELU_ERF;
+    for (int i = 0; i < c.layers; ++i) {
+        if (!t->set[i]) return OV_ERR_INVALID;
+        const ov_block_weights& w = t->blocks[i];
+        int rc;
+        if ((rc = OV_PROF(OV_PROF_LN, ov_layernorm(x, OV_BF16, D, w.ln1_w, w.ln1_b, h, OV_BF16, D, M, D, c.ln_eps, stream)))) return rc;
+        if ((rc = OV_PROF(OV_PROF_GEMM_QKV, ov_gemm(h, D, w.qkv_w, D, w.qkv_b, big, 3 * D, M, 3 * D, D, OV_EPI_BIAS, nullptr, 0, 0, 0,
+                                                    0, stream))))
+            return rc;
+        if ((rc = OV_PROF(OV_PROF_ATTN, ov_attention(big, 3 * D, h, D, B, L, H, hd, scale, stream)))) return rc;
+        if ((rc = OV_PROF(OV_PROF_GEMM_OUT, ov_gemm(h, D, w.out_w, D, w.out_b, x, D, M, D, D, OV_EPI_BIAS_RESIDUAL, x, D, 0, 0, 0,
+                                                    stream))))
+            return rc;
+        if ((rc = OV_PROF(OV_PROF_LN, ov_layernorm(x, OV_BF16, D, w.ln2_w, w.ln2_b, h, OV_BF16, D, M, D, c.ln_eps, stream)))) return rc;
+        if ((rc = OV_PROF(OV_PROF_GEMM_FC, ov_gemm(h, D, w.fc_w, D, w.fc_b, big, c.mlp_pad, M, c.mlp_pad, D, gelu, nullptr, 0, 0, 0, 0,
+                                                   stream))))
+            return rc;
+        if ((rc = OV_PROF(OV_PROF_GEMM_PROJ, ov_gemm(big, c.mlp_pad, w.proj_w, c.mlp_pad, w.proj_b, x, D, M, D, c.mlp_pad,
+                                                     OV_EPI_BIAS_RESIDUAL, x, D, 0, 0, 0, stream))))
+            return rc;
+    }
+    return OV_OK;
+}
+
+extern "C" size_t ov_vision_workspace_bytes(const ov_tower* t, const ov_vision_head* h, int B) {
+    if (!t || !h || B <= 0 || h->patch_size <= 0) return 0;
+    return vision_ws(t, h, B).total;
+}
+
+extern "C" int ov_vision_embed(const ov_tower* t, const ov_vision_head* h, const void* image, int img_dtype, int B,
+                               ov_bf16* x, void* workspace, size_t workspace_bytes, ov_stream_t stream) {
+    if (!t || !h || !image || !x || !workspace || B <= 0) return OV_ERR_INVALID;
+    const int g = h->image_size / h->patch_size, L = g * g + 1, D = t->cfg.width;
+    const size_t need = (size_t)B * g * g * h->kpad * 2;
+    if (workspace_bytes < need) return OV_ERR_WORKSPACE;
+    if (h->kpad % 64 || h->kpad < 3 * h->patch_size * h->patch_size) return OV_ERR_INVALID;
+    ov_bf16* patches = (ov_bf16*)workspace;
+    int rc;
+    if ((rc = ov_im2col_patches(image, img_dtype, patches, B, h->image_size, h->patch_size, h->kpad, stream))) return rc;
+    // conv1 as a GEMM; epilogue adds pos-emb rows 1..g*g (broadcast over the batch) and skips one cls row per image
+    if ((rc = ov_gemm(patches, h->kpad, h->conv_w, h->kpad, nullptr, x, D, (int64_t)B * g * g, D, h->kpad,
+                      OV_EPI_BIAS_RESIDUAL, h->pos, D, g * g, g * g, 1, stream)))
+        return rc;
+    return ov_cls_rows(x, D, h->cls, h->pos_f32, B, L, D, stream);
+}
+
+extern "C" int ov_vision_head_forward(const ov_tower* t, const ov_vision_head* h, const ov_bf16* x, int B, float* features,
+                                      int normalize, void* workspace, size_t workspace_bytes, ov_stream_t stream) {
+    if (!t || !h || !x || !features || !workspace || B <= 0) return OV_ERR_INVALID;
+    const int g = h->image_size / h->patch_size, L = g * g + 1, D = t->cfg.width, E = h->embed_dim, EP = h->embed_pad;
+    if (EP % 8 || EP < E) return OV_ERR_INVALID;
+    if (!h->final_ln_after_pool) return OV_ERR_UNSUPPORTED;       // OpenVision: pool -> LN (transformer.py:638-640)
+    const size_t o_pooled = 0, o_ln = align_up((size_t)B * D * 4, 256), o_feat = o_ln + align_up((size_t)B * D * 2, 256);
+    if (workspace_bytes < o_feat + (size_t)B * EP * 2) return OV_ERR_WORKSPACE;
+    float* pooled = (float*)((char*)workspace + o_pooled);
+    ov_bf16* ln = (ov_bf16*)((char*)workspace + o_ln);
+    ov_bf16* feat = (ov_bf16*)((char*)workspace + o_feat);
+    int rc;
+    if (h->pool_avg) {
+        if ((rc = ov_mean_pool(x, D, pooled, B, L, D, 1, stream))) return rc;
+        if ((rc = ov_layernorm(pooled, OV_F32, D, h->ln_post_w, h->ln_post_b, ln, OV_BF16, D, B, D, t->cfg.ln_eps, stream))) return rc;
+    } else {
+        if ((rc = ov_layernorm(x, OV_BF16, (int64_t)L * D, h->ln_post_w, h->ln_post_b, ln, OV_BF16, D, B, D, t->cfg.ln_eps, stream)))
+            return rc;
+    }
+    if ((rc = ov_gemm(ln, D, h->proj_t, D, nullptr, feat, EP, B, EP, D, OV_EPI_BIAS, nullptr, 0, 0, 0, 0, stream))) return rc;
+    if (normalize) return ov_l2norm(feat, OV_BF16, EP, features, E, B, E, stream);
+    return ov_convert(feat, OV_BF16, EP, features, OV_F32, E, B, E, stream);
+}
+
+extern "C" int ov_encode_image(const ov_tower* t, const ov_vision_head* h, const void* image, int img_dtype, int B,
+                               float* features, int normalize, void* workspace, size_t workspace_bytes, ov_stream_t stream) {
+    if (!t || !h || !image || !features || !workspace || B <= 0) return OV_ERR_INVALID;
+    const VisionWs w = vision_ws(t, h, B);
+    if (workspace_bytes < w.total) return OV_ERR_WORKSPACE;
+    const int g = h->image_size / h->patch_size, L = g * g + 1;
+    char* ws = (char*)workspace;
+    ov_bf16* x = (ov_bf16*)(ws + w.x);
+    const size_t tower_bytes = ov_tower_workspace_bytes(t, B, L);
+    int rc;
+    // the im2col buffer aliases the (not yet used) tower workspace
+    if ((size_t)B * g * g * h->kpad * 2 > tower_bytes) return OV_ERR_WORKSPACE;
+    if ((rc = ov_vision_embed(t, h, image, img_dtype, B, x, ws + w.tower, tower_bytes, stream))) return rc;
+    if ((rc = ov_tower_forward(t, x, B, L, ws + w.tower, tower_bytes, stream))) return rc;
+    return ov_vision_head_forward(t, h, x, B, features, normalize, ws + w.pooled, w.total - w.pooled, stream);
+}
+
+extern "C" size_t ov_text_workspace_bytes(const ov_tower* t, const ov_text_head* h, int B) {
+    if (!t || !h || B <= 0) return 0;
+    return text_ws(t, h, B).total;
+}
+
+extern "C" int ov_encode_text(const ov_tower* t, const ov_text_head* h, const int64_t* tokens, int B, float* features,
+                              int normalize, int* err_flag, void* workspace, size_t workspace_bytes, ov_stream_t stream) {
+    if (!t || !h || !tokens || !features || !workspace || B <= 0) return OV_ERR_INVALID;
+    const TextWs w = text_ws(t, h, B);
+    if (workspace_bytes < w.total) return OV_ERR_WORKSPACE;
+    const int T = h->context_length, D = t->cfg.width, E = h->embed_dim, EP = (E + 7) / 8 * 8;
+    char* ws = (char*)workspace;
+    ov_bf16* x = (ov_bf16*)(ws + w.x);
+    ov_bf16* last = (ov_bf16*)(ws + w.last);
+    ov_bf16* ln = (ov_bf16*)(ws + w.lnrow);
+    ov_bf16* feat = (ov_bf16*)(ws + w.feat);
+    int rc;
+    if ((rc = ov_text_embed(tokens, h->token_embedding, h->pos, x, D, B, T, D, h->vocab_size, err_flag, stream))) return rc;
+    if ((rc = ov_tower_forward(t, x, B, T, ws + w.tower, ov_tower_workspace_bytes(t, B, T), stream))) return rc;
+    // ln_final is per-token, so only the pooled row needs it (model.py:276-277)
+    if ((rc = ov_gather_rows(x, D, last, D, B, T, h->pool_last ? T - 1 : 0, D, stream))) return rc;
+    if ((rc = ov_layernorm(last, OV_BF16, D, h->ln_final_w, h->ln_final_b, ln, OV_BF16, D, B, D, t->cfg.ln_eps, stream))) return rc;
+    if ((rc = ov_gemm(ln, D, h->proj_t, D, nullptr, feat, EP, B, EP, D, OV_EPI_BIAS, nullptr, 0, 0, 0, 0, stream))) return rc;
+    if (normalize) return ov_l2norm(feat, OV_BF16, EP, features, E, B, E, stream);
+    return ov_convert(feat, OV_BF16, EP, features, OV_F32, E, B, E, stream);
+}

@@ -1,0 +1,51 @@
+"""Thin test-side wrappers: torch tensors -> C ABI calls of libovhip.so (granular operators)."""
+import ctypes as C
+
+import torch
+
+from openvision_amd import _lib
+from openvision_amd._lib import ptr, stream_ptr, check, OV_BF16, OV_F32
+
+
+def _flag(t):
+    return OV_F32 if t.dtype == torch.float32 else OV_BF16
+
+
+def layernorm(x, g, b, eps=1e-6, out_dtype=None):
+    lib = _lib.load()
+    x2 = x.contiguous().view(-1, x.shape[-1])
+    y = torch.empty(x2.shape, dtype=out_dtype or x.dtype, device=x.device)
+    check(lib.ov_layernorm(ptr(x2), _flag(x2), x2.shape[1], ptr(g), ptr(b), ptr(y), _flag(y), x2.shape[1], x2.shape[0],
+                           x2.shape[1], eps, stream_ptr()))
+    return y.view(x.shape)
+
+
+def gemm(a, w, bias=None, epi=0, resid=None, out=None, out_group=0, resid_mod=0, resid_off=0, out_rows=None):
+    lib = _lib.load()
+    m, k = a.shape
+    n = w.shape[0]
+    if out is None:
+        out = torch.zeros(out_rows or m, n, dtype=torch.bfloat16, device=a.device)
+    check(lib.ov_gemm(ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(out), out.stride(0), m, n, k, epi,
+                      ptr(resid), resid.stride(0) if resid is not None else 0, out_group, resid_mod, resid_off, stream_ptr()))
+    return out
+
+
+def attention(qkv, B, L, H, hd=64):
+    lib = _lib.load()
+    out = torch.empty(B * L, H * hd, dtype=torch.bfloat16, device=qkv.device)
+    check(lib.ov_attention(ptr(qkv), qkv.stride(0), ptr(out), out.stride(0), B, L, H, hd, hd ** -0.5, stream_ptr()))
+    return out
+
+
+def clip_loss(img, txt, all_img, all_txt, scale, label_offset):
+    lib = _lib.load()
+    b, e = img.shape
+    n = all_img.shape[0]
+    nb = lib.ov_clip_loss_workspace_bytes(b, n)
+    ws = torch.empty(nb + 16, dtype=torch.uint8, device=img.device)
+    out = torch.empty(1, dtype=torch.float32, device=img.device)
+    terms = torch.empty(4, b, dtype=torch.float32, device=img.device)
+    check(lib.ov_clip_loss(ptr(img), ptr(txt), ptr(all_img), ptr(all_txt), b, n, e, float(scale), label_offset, ptr(out),
+                           ptr(terms), ptr(ws), nb, stream_ptr()))
+    return out[0], terms

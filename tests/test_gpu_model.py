@@ -1,0 +1,139 @@
+"""GPU parity: the drop-in CLIP / ClipLoss surface against the golden vectors produced by the reference.
+
+north_star tolerance: embeddings within 1e-3 cosine of the PyTorch (fp32) reference, top-k indices equal.
+The HIP path computes in bf16 (fp32 accumulate); the reference's own bf16 mode sits ~2e-5 (1-cos) from its
+fp32 mode on these weights (tests/test_oracle_golden.py::test_large_features)."""
+import numpy as np
+import pytest
+import torch
+
+from openvision_amd import preset, synth
+from openvision_amd.model import create_model, logits
+from openvision_amd.loss import ClipLoss
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+COS_TOL = 1e-3
+
+
+def one_minus_cos(a, b):
+    return (1 - torch.nn.functional.cosine_similarity(a.float().cpu(), torch.as_tensor(b).float(), dim=-1)).max().item()
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    cfg = preset("vit-tiny-patch16-160")
+    return create_model(cfg, device=DEV, state_dict=synth.make_state_dict(cfg))
+
+
+def test_tiny_encode_image_text_and_loss(tiny):
+    g = golden("tiny16_160.npz")
+    img, tok = torch.from_numpy(g["images"]).to(DEV), torch.from_numpy(g["tokens"]).to(DEV)
+    fi, ft = tiny.encode_image(img), tiny.encode_text(tok)
+    assert fi.dtype == torch.float32 and fi.shape == (4, 192) and not fi.requires_grad
+    assert one_minus_cos(fi, g["image_features"]) < COS_TOL
+    assert one_minus_cos(ft, g["text_features"]) < COS_TOL
+    ni, nt, s = tiny(img, tok)
+    assert abs(float(s) - float(g["logit_scale_exp"])) < 1e-4
+    np.testing.assert_allclose(ni.norm(dim=-1).cpu().numpy(), 1.0, atol=1e-5)
+    li, lt = tiny.get_logits(img, tok)
+    # logits = 14.29 * cosine: bf16-path error budget 14.29 * ~5e-3
+    np.testing.assert_allclose(li.cpu().numpy(), g["logits_per_image"], atol=0.15)
+    np.testing.assert_allclose(lt.cpu().numpy(), g["logits_per_text"], atol=0.15)
+    loss = ClipLoss()(ni, nt, s)
+    assert abs(float(loss) - float(g["loss"])) < 0.05
+    tiny.check_token_range()
+
+
+def test_tiny_exploded_forward_like_ov_zero_shot_test(tiny):
+    """ov-zero-shot-test.py:103-155 walks the sub-modules; the exploded path must agree with encode_*."""
+    g = golden("tiny16_160.npz")
+    m = tiny
+    image, text = torch.from_numpy(g["images"]).to(DEV), torch.from_numpy(g["tokens"]).to(DEV)
+    x = m.visual.conv1(image)
+    np.testing.assert_allclose(x.cpu().numpy(), g["conv1"], atol=3e-2, rtol=2e-2)
+    x = x.reshape(x.shape[0], x.shape[1], -1).permute(0, 2, 1)
+    cls = m.visual.class_embedding.to(x.dtype) + torch.zeros(x.shape[0], 1, x.shape[-1], dtype=x.dtype, device=x.device)
+    x = torch.cat([cls, x], dim=1)
+    x = x + m.visual.positional_embedding.to(x.dtype)
+    x = m.visual.patch_dropout(x)
+    x = m.visual.ln_pre(x)
+    x = m.visual.transformer(x)
+    assert np.abs(x.cpu().numpy() - g["block11"]).max() < 0.25     # bf16 residual stream over 12 blocks
+    pooled = x[:, 1:].mean(dim=1)
+    pooled = m.visual.ln_post(pooled)
+    feats = pooled @ m.visual.proj
+    assert one_minus_cos(feats, g["image_features"]) < COS_TOL
+    cast = m.transformer.get_cast_dtype()
+    t = m.token_embedding(text).to(cast) + m.positional_embedding[: text.shape[1]].to(cast)
+    t = m.transformer(t, attn_mask=m.attn_mask)
+    t = m.ln_final(t)[:, -1] @ m.text_projection
+    assert one_minus_cos(t, g["text_features"]) < COS_TOL
+
+
+def test_tiny_testcat_table_topk(tiny):
+    g = golden("tiny16_160_testcat.npz")
+    img = torch.from_numpy(g["images"].astype(np.float32)).to(DEV)
+    tok = torch.from_numpy(g["tokens"]).to(DEV)
+    tf = tiny.encode_text(tok, normalize=True)
+    cos = []
+    for i in range(img.shape[0]):                               # batch 1 per image, as the script does
+        cos.append(logits(tiny.encode_image(img[i:i + 1], normalize=True), tf)[0])
+    cos = torch.stack(cos).cpu()
+    np.testing.assert_allclose(cos.numpy(), g["cosine"], atol=1e-2)
+    ref = g["cosine"]
+    order = cos.argsort(dim=-1, descending=True).numpy()
+    for r in range(ref.shape[0]):
+        # top-k order must match wherever the reference's neighbouring gaps exceed the bf16 budget
+        srt = np.sort(ref[r])[::-1]
+        k = 0
+        while k + 1 < len(srt) and srt[k] - srt[k + 1] > 2e-2:
+            k += 1
+        assert np.array_equal(order[r][:k], g["argsort"][r][:k])
+
+
+def test_batch_invariance_and_determinism(tiny):
+    img = synth.make_images(9, 160, seed=5).to(DEV)
+    a = tiny.encode_image(img)
+    b = torch.cat([tiny.encode_image(img[:4]), tiny.encode_image(img[4:])])
+    assert torch.equal(a, b)                                     # row results do not depend on batch composition
+    assert torch.equal(a, tiny.encode_image(img))                # bitwise repeatable
+
+
+@pytest.mark.timeout(900)
+def test_large14_224_features():
+    cfg = preset("vit-large-patch14-224")
+    m = create_model(cfg, device=DEV, state_dict=synth.make_state_dict(cfg))
+    g = golden("large14_224.npz")
+    img = torch.from_numpy(g["images"].astype(np.float32)).to(DEV)
+    tok = torch.from_numpy(g["tokens"]).to(DEV)
+    fi, ft = m.encode_image(img), m.encode_text(tok)
+    assert one_minus_cos(fi, g["image_features"]) < COS_TOL
+    assert one_minus_cos(ft, g["text_features"]) < COS_TOL
+    # same-precision comparison: against the reference's own bf16 mode
+    assert one_minus_cos(fi, g["image_features_refbf16"]) < COS_TOL
+    ni, nt, s = m(img, tok)
+    assert abs(float(ClipLoss()(ni, nt, s)) - float(g["loss"])) < 0.05
+    # full-size property checks (config #2 shape, B=256 would need the whole-batch oracle): batch invariance at B=32
+    big = synth.make_images(32, 224, seed=3).to(DEV).to(torch.bfloat16)
+    fb = m.encode_image(big)
+    assert torch.equal(fb[:7], m.encode_image(big[:7]))
+    assert torch.isfinite(fb).all()
+
+
+@pytest.mark.timeout(900)
+def test_small8_384_long_sequence():
+    cfg = preset("vit-small-patch8-384")
+    m = create_model(cfg, device=DEV, state_dict=synth.make_state_dict(cfg))
+    g = golden("small8_384.npz")
+    fi = m.encode_image(torch.from_numpy(g["images"].astype(np.float32)).to(DEV))
+    assert one_minus_cos(fi, g["image_features"]) < COS_TOL
+
+
+def test_no_cpu_fallback(tiny):
+    from openvision_amd._lib import OvhipError
+    with pytest.raises(OvhipError):
+        tiny.encode_image(torch.zeros(1, 3, 160, 160))
+    with pytest.raises(OvhipError):
+        ClipLoss()(torch.zeros(2, 192), torch.zeros(2, 192), 1.0)

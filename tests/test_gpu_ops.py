@@ -1,0 +1,133 @@
+"""GPU parity: each HIP operator (through the C ABI) against the oracle on the same seeded inputs.
+
+Tolerances are stated per test.  bf16 has 8 significant bits (eps = 2^-8 = 3.9e-3 relative), so an
+operator with bf16 output is compared with rtol ~ 1e-2 against the oracle evaluated in fp32 on the SAME
+bf16-rounded inputs; fp32-output operators (LN stats, l2norm, logits, loss) get fp32-level tolerances."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import clip_ref as R
+import hipops as H
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+@pytest.mark.parametrize("rows,D", [(7, 192), (513, 768), (1000, 1024), (33, 1152), (5, 4096), (3, 384)])
+def test_layernorm_bf16(rows, D):
+    x = (rnd(rows, D, seed=1) * 2 + 0.5).to(torch.bfloat16)
+    g, b = rnd(D, seed=2) * 0.1 + 1, rnd(D, seed=3) * 0.1
+    y = H.layernorm(x.to(DEV), g.to(DEV), b.to(DEV)).float().cpu()
+    ref = R.layer_norm(x.float(), g, b)
+    # output rounded to bf16: |err| <= 2^-8 |y| + small
+    np.testing.assert_allclose(y.numpy(), ref.numpy(), rtol=8e-3, atol=8e-3)
+
+
+def test_layernorm_fp32_io_matches_oracle_tightly():
+    x = rnd(64, 1024, seed=4) * 3 - 1
+    g, b = rnd(1024, seed=5) * 0.1 + 1, rnd(1024, seed=6) * 0.1
+    y = H.layernorm(x.to(DEV), g.to(DEV), b.to(DEV)).cpu()
+    np.testing.assert_allclose(y.numpy(), R.layer_norm(x, g, b).numpy(), rtol=1e-5, atol=2e-5)
+
+
+GEMM_SHAPES = [(256, 256, 64), (300, 200, 128), (1, 8, 64), (257 * 3, 1024, 1024), (505, 576, 192), (640, 4096, 1024),
+               (512, 1024, 4096), (100, 768, 640)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_bias(M, N, K):
+    a, w, bias = rnd(M, K, seed=7).to(torch.bfloat16), (rnd(N, K, seed=8) / K ** 0.5).to(torch.bfloat16), rnd(N, seed=9)
+    c = H.gemm(a.to(DEV), w.to(DEV), bias.to(DEV)).float().cpu()
+    ref = a.float() @ w.float().T + bias
+    np.testing.assert_allclose(c.numpy(), ref.numpy(), rtol=1e-2, atol=1e-2)
+
+
+@pytest.mark.parametrize("epi,tanh", [(1, False), (2, True)])
+def test_gemm_gelu(epi, tanh):
+    M, N, K = 333, 768, 192
+    a, w, bias = rnd(M, K, seed=10).to(torch.bfloat16), (rnd(N, K, seed=11) / K ** 0.5).to(torch.bfloat16), rnd(N, seed=12)
+    c = H.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), epi=epi).float().cpu()
+    ref = R.gelu(a.float() @ w.float().T + bias, tanh)
+    np.testing.assert_allclose(c.numpy(), ref.numpy(), rtol=1e-2, atol=1e-2)
+
+
+def test_gemm_residual_inplace():
+    M, N, K = 514, 1024, 1024
+    a, w, bias = rnd(M, K, seed=13).to(torch.bfloat16), (rnd(N, K, seed=14) / K ** 0.5).to(torch.bfloat16), rnd(N, seed=15)
+    x = rnd(M, N, seed=16).to(torch.bfloat16)
+    xd = x.to(DEV).clone()
+    H.gemm(a.to(DEV), w.to(DEV), bias.to(DEV), epi=3, resid=xd, out=xd)
+    ref = x.float() + (a.float() @ w.float().T + bias)
+    np.testing.assert_allclose(xd.float().cpu().numpy(), ref.numpy(), rtol=1e-2, atol=2e-2)
+
+
+def test_gemm_patch_embed_row_maps():
+    B, g2, D, K = 3, 100, 192, 768
+    a, w = rnd(B * g2, K, seed=17).to(torch.bfloat16), (rnd(D, K, seed=18) / K ** 0.5).to(torch.bfloat16)
+    pos = rnd(g2 + 1, D, seed=19).to(torch.bfloat16)
+    out = torch.zeros(B * (g2 + 1), D, dtype=torch.bfloat16, device=DEV)
+    H.gemm(a.to(DEV), w.to(DEV), None, epi=3, resid=pos.to(DEV), out=out, out_group=g2, resid_mod=g2, resid_off=1)
+    ref = (a.float() @ w.float().T).view(B, g2, D) + pos[1:].float()
+    got = out.float().cpu().view(B, g2 + 1, D)
+    np.testing.assert_allclose(got[:, 1:].numpy(), ref.numpy(), rtol=1e-2, atol=1e-2)
+    assert float(got[:, 0].abs().max()) == 0.0           # cls rows untouched
+
+
+@pytest.mark.parametrize("B,L,H_", [(2, 257, 16), (3, 101, 3), (2, 80, 12), (1, 32, 1), (1, 577, 2), (1, 2305, 2)])
+def test_attention(B, L, H_):
+    D = H_ * 64
+    qkv = rnd(B * L, 3 * D, seed=20).to(torch.bfloat16)
+    o = H.attention(qkv.to(DEV), B, L, H_).float().cpu().view(B, L, D)
+    q, k, v = qkv.float().view(B, L, 3 * D).split(D, dim=-1)
+    sp = lambda t: t.reshape(B, L, H_, 64).transpose(1, 2)
+    p = torch.softmax(sp(q) * 0.125 @ sp(k).transpose(-1, -2), dim=-1)
+    ref = (p @ sp(v)).transpose(1, 2).reshape(B, L, D)
+    # P is rounded to bf16 before P.V and the output is bf16: abs err ~ 2^-8 * |v| scale
+    np.testing.assert_allclose(o.numpy(), ref.numpy(), rtol=2e-2, atol=1.5e-2)
+
+
+def test_attention_online_softmax_rescale_branch():
+    """Force the running max to jump late (a spiked key in the LAST tile) — cdna guide rule 26."""
+    B, L, H_ = 1, 257, 1
+    qkv = rnd(L, 192, seed=21).to(torch.bfloat16)
+    qkv[250, 64:128] = qkv[3, 0:64] * 6.0            # key 250 aligned with query 3 -> huge logit in the last tile
+    o = H.attention(qkv.to(DEV), B, L, H_).float().cpu()
+    q, k, v = qkv.float().split(64, dim=-1)
+    ref = torch.softmax(q * 0.125 @ k.T, dim=-1) @ v
+    np.testing.assert_allclose(o.numpy(), ref.numpy(), rtol=2e-2, atol=1.5e-2)
+
+
+@pytest.mark.parametrize("b,N,E,off", [(16, 16, 192, 0), (4, 16, 192, 8), (256, 256, 768, 0), (100, 700, 384, 300),
+                                       (33, 4100, 768, 4000)])
+def test_clip_loss_terms(b, N, E, off):
+    ai = torch.nn.functional.normalize(rnd(N, E, seed=22), dim=-1)
+    at = torch.nn.functional.normalize(ai * 0.5 + rnd(N, E, seed=23) * 0.05, dim=-1)
+    img, txt = ai[off:off + b].contiguous(), at[off:off + b].contiguous()
+    s = 1 / 0.07
+    loss, terms = H.clip_loss(img.to(DEV), txt.to(DEV), ai.to(DEV), at.to(DEV), s, off)
+    rank_loss = (torch.nn.functional.cross_entropy(s * img @ at.T, torch.arange(b) + off) +
+                 torch.nn.functional.cross_entropy(s * txt @ ai.T, torch.arange(b) + off)) / 2
+    li = s * img @ at.T
+    np.testing.assert_allclose(terms[0].cpu().numpy(), torch.logsumexp(li, 1).numpy(), rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(terms[1].cpu().numpy(), li[torch.arange(b), torch.arange(b) + off].numpy(), rtol=1e-5, atol=2e-5)
+    assert abs(float(loss) - float(rank_loss)) < 2e-5
+
+
+def test_clip_loss_golden_reference_ranks():
+    from conftest import golden
+    g = golden("cliploss_ws.npz")
+    img, txt, s = torch.from_numpy(g["img"]), torch.from_numpy(g["txt"]), float(g["scale"])
+    loss, _ = H.clip_loss(img.to(DEV), txt.to(DEV), img.to(DEV), txt.to(DEV), s, 0)
+    assert abs(float(loss) - float(g["loss_ws1"])) < 1e-5
+    for ws in (2, 8):
+        b = 16 // ws
+        for r in range(ws):
+            l, _ = H.clip_loss(img[r * b:(r + 1) * b].contiguous().to(DEV), txt[r * b:(r + 1) * b].contiguous().to(DEV),
+                               img.to(DEV), txt.to(DEV), s, r * b)
+            assert abs(float(l) - float(g[f"local_losses_ws{ws}"][r])) < 1e-5
