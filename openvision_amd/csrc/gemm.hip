@@ -16,6 +16,7 @@
 //   * workgroup id -> tile map is XCD-aware: each XCD's L2 sees a contiguous run of tiles that walk n
 //     fastest, so the 32 tiles resident on an XCD share A row-panels and the whole of W.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -33,6 +34,66 @@ struct GemmArgs {
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+
+// ---- shared epilogue: acc[i][j][r] = C[m0 + wm*128 + i*16 + fr][n0 + wn*64 + j*16 + fq*4 + r] -------------------
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4_t (&acc)[8][4], char* smem, int64_t m0, int n0,
+                                              int wave, int lane) {
+    const int wm = wave >> 2, wn = wave & 3;
+    const int fr = lane & 15, fq = lane >> 4;
+    __syncthreads();                                        // last tile's LDS reads are done
+    char* ep = smem + wave * 16384;                         // this wave's 128 x 64 bf16 image
+    float bv[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int nn = n0 + wn * 64 + j * 16 + fq * 4;
+        if (g.bias != nullptr && nn < g.N) {
+            const float4 b4 = *(const float4*)(g.bias + nn);
+            bv[j][0] = b4.x; bv[j][1] = b4.y; bv[j][2] = b4.z; bv[j][3] = b4.w;
+        } else {
+            bv[j][0] = bv[j][1] = bv[j][2] = bv[j][3] = 0.f;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int ml = i * 16 + fr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x = acc[i][j][r] + bv[j][r];
+                if (EPI == OV_EPI_BIAS_GELU_ERF) x = gelu_erf_f(x);
+                if (EPI == OV_EPI_BIAS_GELU_TANH) x = gelu_tanh_f(x);
+                v[r] = x;
+            }
+            u32x2_t p = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            const int c = j * 2 + (fq >> 1);
+            *(u32x2_t*)(ep + ml * 128 + ((c ^ (ml & 7)) << 4) + (fq & 1) * 8) = p;
+        }
+    }
+    __syncthreads();
+    const int er = lane >> 3, ec = lane & 7;
+    const int n = n0 + wn * 64 + ec * 8;
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const int row = it * 8 + er;
+        u32x4_t v = *(const u32x4_t*)(ep + row * 128 + ((ec ^ (row & 7)) << 4));
+        const int64_t m = m0 + wm * 128 + row;
+        if (m < g.M && n < g.N) {
+            if (EPI == OV_EPI_BIAS_RESIDUAL) {
+                const int64_t rrow = g.resid_mod ? (m % g.resid_mod) + g.resid_off : m;
+                const u32x4_t rv = *(const u32x4_t*)(g.R + rrow * g.ldr + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    v[e] = pack_bf16x2(bf16lo_to_f32(v[e]) + bf16lo_to_f32(rv[e]),
+                                       bf16hi_to_f32(v[e]) + bf16hi_to_f32(rv[e]));
+            }
+            const int64_t orow = g.out_group ? m + m / g.out_group + 1 : m;
+            *(u32x4_t*)(g.C + orow * g.ldc + n) = v;
+        }
+    }
+}
 
 template <int EPI>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_256x256(const GemmArgs g) {
@@ -113,10 +174,147 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_256x256(const GemmArgs 
         }
     }
 
-    // ---- epilogue --------------------------------------------------------------------------------
-    // acc[i][j][r] = C[m0 + wm*128 + i*16 + fr][n0 + wn*64 + j*16 + fq*4 + r]
-    __syncthreads();                                        // last tile's LDS reads are done
-    char* ep = smem + wave * 16384;                         // this wave's 128 x 64 bf16 image
+    gemm_epilogue<EPI>(g, acc, smem, m0, n0, wave, lane);
+}
+
+// =====================================================================================================
+// Ping-pong kernel (default).  Same tile and epilogue as above, different main loop:
+//   * each K-tile (BK = 64) is staged as FOUR 16-KiB pieces -- (A,k 0-31) (W,k 0-31) (A,k 32-63) (W,k 32-63) --
+//     one piece per phase, one K-tile ahead, with a COUNTED s_waitcnt vmcnt(4) at phases 1 and 3 (never 0 in the
+//     loop) and raw s_barrier, so two pieces stay in flight across every barrier;
+//   * a K-tile is four phases of 16 MFMAs: (k-half, m-half) = (0,0) (0,1) (1,0) (1,1); each phase is a LOAD
+//     segment (4-8 ds_read_b128 + 2 global_load_lds) and a COMPUTE segment (16 MFMAs), separated by barriers;
+//   * waves 4-7 (the lower 128 rows) run ONE barrier behind waves 0-3, so on every SIMD one wave is in its COMPUTE
+//     segment while its partner is in its LOAD segment: the matrix pipe sees back-to-back MFMA clusters instead of
+//     both waves stalling on LDS at once.
+// LDS map (128 KiB): buffer b in {0,1} at b*64 KiB, then [A k0][W k0][A k1][W k1] x 16 KiB; a piece is 256 rows x 64 B,
+// 16-B chunk c of row r stored at chunk c ^ f((r >> 2) & 3), f = {0,2,3,1}: conflict-free for the 16x16x32 operand reads.
+// Hazards (interval = span between two consecutive barriers; wave group 1 lags group 0 by one interval):
+//   RAW  a piece issued in phase p of tile T is waited for (counted vmcnt) in phase 3 (p<2) or phase 1 of T+1 (p>=2),
+//        and first read >= one barrier after EVERY wave has passed that wait;
+//   WAR  a slot is re-staged >= 4 intervals after its last ds_read was issued (those reads are consumed by the
+//        MFMAs of the reader's next COMPUTE segment, i.e. before its next barrier).
+constexpr int PIECE_BYTES = 256 * 64;          // 16 KiB
+
+__device__ __forceinline__ int swz4(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }
+
+template <int EPI>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp(const GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int nwg = g.tiles_m * g.tiles_n;
+    const int bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    const int tm = wgid / g.tiles_n, tn = wgid - tm * g.tiles_n;
+    const int64_t m0 = (int64_t)tm * BM;
+    const int n0 = tn * BN;
+
+    // staging: LDS chunk q = i*512 + tid of a piece holds row q>>2, logical chunk (q&3) ^ f(row)
+    const int srow = tid >> 2;
+    const int schunk = (tid & 3) ^ swz4(srow);
+    const ov_bf16* asrc[2];
+    const ov_bf16* wsrc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int64_t ar = m0 + i * 128 + srow;
+        ar = ar < g.M ? ar : g.M - 1;
+        int wr = n0 + i * 128 + srow;
+        wr = wr < g.N ? wr : g.N - 1;
+        asrc[i] = g.A + ar * g.lda + schunk * 8;
+        wsrc[i] = g.W + (int64_t)wr * g.ldw + schunk * 8;
+    }
+    char* const sbase = smem + wave * 1024;
+    // piece j of the K-tile starting at k0 -> buffer buf
+    auto stage_piece = [&](int buf, int j, int k0) {
+        char* dst = sbase + buf * STAGE_BYTES + j * PIECE_BYTES;
+        const int kk = k0 + (j >> 1) * 32;
+        if (j & 1) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[0] + kk), (lptr_t)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[1] + kk), (lptr_t)(dst + 8192), 16, 0, 0);
+        } else {
+            __builtin_amdgcn_global_load_lds((gptr_t)(asrc[0] + kk), (lptr_t)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(asrc[1] + kk), (lptr_t)(dst + 8192), 16, 0, 0);
+        }
+    };
+
+    const int wm = wave >> 2, wn = wave & 3;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int lsw = (fq ^ swz4(fr)) << 4;
+    const int a_lane = (wm * 128 + fr) * 64 + lsw;                 // + piece(A,kh) + i*1024
+    const int w_lane = PIECE_BYTES + (wn * 64 + fr) * 64 + lsw;    // + piece pair(kh) + j*1024
+
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nt = g.K / BK;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) stage_piece(0, j, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();                     // stagger the lower wave group by one interval
+
+    bf16x8_t af[4], wf[4];
+    for (int t = 0; t < nt; ++t) {
+        const char* s = smem + (t & 1) * STAGE_BYTES;
+        const bool more = (t + 1 < nt);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int kh = p >> 1, mh = p & 1;
+            // ---------------- LOAD segment ----------------
+            const char* sp = s + kh * (2 * PIECE_BYTES);
+            if (mh == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wf[j] = *(const bf16x8_t*)(sp + w_lane + j * 1024);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8_t*)(sp + a_lane + (mh * 4 + i) * 1024);
+            if (more) stage_piece((t + 1) & 1, p, (t + 1) * BK);
+            if (p & 1) {
+                if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---------------- COMPUTE segment ----------------
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[mh * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[mh * 4 + i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();                     // re-align the two wave groups
+    gemm_epilogue<EPI>(g, acc, smem, m0, n0, wave, lane);
+}
+
+// =====================================================================================================
+// Persistent ping-pong kernel (default).  One workgroup per CU walks a static, XCD-contiguous list of output tiles.
+// On top of the ping-pong main loop above:
+//   * the LAST K-tile of a tile stages K-tile 0 of the NEXT tile into the free LDS buffer, so the next main loop
+//     starts with its operands already on chip (no per-tile prologue latency, no relaunch);
+//   * the epilogue transposes through the 64 KiB buffer the last K-tile occupied (8 KiB per wave, two 64-row passes,
+//     wave-local), leaving the prefetched buffer untouched; its global stores are issued and the next tile's MFMAs
+//     start while they drain, so store bursts of different CUs no longer line up in time;
+//   * the two wave groups re-align for the epilogue (both halves of every SIMD share the VALU work) and re-stagger
+//     by one barrier afterwards.
+template <int EPI>
+__device__ __forceinline__ void epilogue_2pass(const GemmArgs& g, f32x4_t (&acc)[8][4], char* ep, int64_t m0, int n0,
+                                               int wave, int lane, bool drain_loads_before_stores, bool resid_folded) {
+    const int wm = wave >> 2, wn = wave & 3;
+    const int fr = lane & 15, fq = lane >> 4;
     float bv[4][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -128,51 +326,231 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_256x256(const GemmArgs 
             bv[j][0] = bv[j][1] = bv[j][2] = bv[j][3] = 0.f;
         }
     }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int ml = i * 16 + fr;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float x = acc[i][j][r] + bv[j][r];
-                if (EPI == OV_EPI_BIAS_GELU_ERF) x = gelu_erf_f(x);
-                if (EPI == OV_EPI_BIAS_GELU_TANH) x = gelu_tanh_f(x);
-                v[r] = x;
-            }
-            u32x2_t p = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-            const int c = j * 2 + (fq >> 1);
-            *(u32x2_t*)(ep + ml * 128 + ((c ^ (ml & 7)) << 4) + (fq & 1) * 8) = p;
-        }
-    }
-    __syncthreads();
     const int er = lane >> 3, ec = lane & 7;
     const int n = n0 + wn * 64 + ec * 8;
-#pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-        const int row = it * 8 + er;
-        u32x4_t v = *(const u32x4_t*)(ep + row * 128 + ((ec ^ (row & 7)) << 4));
-        const int64_t m = m0 + wm * 128 + row;
-        if (m < g.M && n < g.N) {
-            if (EPI == OV_EPI_BIAS_RESIDUAL) {
-                const int64_t rrow = g.resid_mod ? (m % g.resid_mod) + g.resid_off : m;
-                const u32x4_t rv = *(const u32x4_t*)(g.R + rrow * g.ldr + n);
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    v[e] = pack_bf16x2(bf16lo_to_f32(v[e]) + bf16lo_to_f32(rv[e]),
-                                       bf16hi_to_f32(v[e]) + bf16hi_to_f32(rv[e]));
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ml = i * 16 + fr;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = acc[h * 4 + i][j][r] + bv[j][r];
+                    if (EPI == OV_EPI_BIAS_GELU_ERF) x = gelu_erf_f(x);
+                    if (EPI == OV_EPI_BIAS_GELU_TANH) x = gelu_tanh_f(x);
+                    v[r] = x;
+                }
+                u32x2_t pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                const int c = j * 2 + (fq >> 1);
+                *(u32x2_t*)(ep + ml * 128 + ((c ^ (ml & 7)) << 4) + (fq & 1) * 8) = pk;
             }
-            const int64_t orow = g.out_group ? m + m / g.out_group + 1 : m;
-            *(u32x4_t*)(g.C + orow * g.ldc + n) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // wave-local hand-over (DS ops of one wave are in order)
+        u32x4_t v[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = it * 8 + er;
+            v[it] = *(const u32x4_t*)(ep + row * 128 + ((ec ^ (row & 7)) << 4));
+        }
+        if (EPI == OV_EPI_BIAS_RESIDUAL && !resid_folded) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int64_t m = m0 + wm * 128 + h * 64 + it * 8 + er;
+                if (m < g.M && n < g.N) {
+                    const int64_t rrow = g.resid_mod ? (m % g.resid_mod) + g.resid_off : m;
+                    const u32x4_t rv = *(const u32x4_t*)(g.R + rrow * g.ldr + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        v[it][e] = pack_bf16x2(bf16lo_to_f32(v[it][e]) + bf16lo_to_f32(rv[e]),
+                                               bf16hi_to_f32(v[it][e]) + bf16hi_to_f32(rv[e]));
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // pass-h reads done before pass-(h+1) writes reuse the image
+        if (h == 0 && drain_loads_before_stores)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile's K-tile 0 has landed; nothing older than the stores
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int64_t m = m0 + wm * 128 + h * 64 + it * 8 + er;
+            if (m < g.M && n < g.N) {
+                const int64_t orow = g.out_group ? m + m / g.out_group + 1 : m;
+                *(u32x4_t*)(g.C + orow * g.ldc + n) = v[it];
+            }
         }
     }
 }
 
 template <int EPI>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist(const GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- static persistent schedule: XCD x owns a contiguous run of tiles (n fastest), its workgroups stride it ----
+    const int nwg = g.tiles_m * g.tiles_n;
+    const int G = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, li = bid >> 3;
+    const int q8 = nwg >> 3, r8 = nwg & 7;
+    const int xstart = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int xcnt = q8 + (xcd < r8 ? 1 : 0);
+    const int nper = (G - xcd + 7) >> 3;
+    int tcur = li;
+    if (tcur >= xcnt) return;
+
+    const int srow = tid >> 2;
+    const int schunk = (tid & 3) ^ swz4(srow);
+    const ov_bf16* asrc[2];
+    const ov_bf16* wsrc[2];
+    const ov_bf16* nasrc[2];
+    const ov_bf16* nwsrc[2];
+    int64_t m0, nm0 = 0;
+    int n0, nn0 = 0;
+    auto set_tile = [&](int trel, const ov_bf16* (&as)[2], const ov_bf16* (&ws)[2], int64_t& mm, int& nn) {
+        const int wg = xstart + trel;
+        const int tm = wg / g.tiles_n, tn = wg - tm * g.tiles_n;
+        mm = (int64_t)tm * BM;
+        nn = tn * BN;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int64_t ar = mm + i * 128 + srow;
+            ar = ar < g.M ? ar : g.M - 1;
+            int wr = nn + i * 128 + srow;
+            wr = wr < g.N ? wr : g.N - 1;
+            as[i] = g.A + ar * g.lda + schunk * 8;
+            ws[i] = g.W + (int64_t)wr * g.ldw + schunk * 8;
+        }
+    };
+    char* const sbase = smem + wave * 1024;
+    auto stage_piece = [&](const ov_bf16* const (&as)[2], const ov_bf16* const (&ws)[2], int buf, int j, int k0) {
+        char* dst = sbase + buf * STAGE_BYTES + j * PIECE_BYTES;
+        const int kk = k0 + (j >> 1) * 32;
+        if (j & 1) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(ws[0] + kk), (lptr_t)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(ws[1] + kk), (lptr_t)(dst + 8192), 16, 0, 0);
+        } else {
+            __builtin_amdgcn_global_load_lds((gptr_t)(as[0] + kk), (lptr_t)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(as[1] + kk), (lptr_t)(dst + 8192), 16, 0, 0);
+        }
+    };
+
+    const int wm = wave >> 2, wn = wave & 3;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int lsw = (fq ^ swz4(fr)) << 4;
+    const int a_lane = (wm * 128 + fr) * 64 + lsw;
+    const int w_lane = PIECE_BYTES + (wn * 64 + fr) * 64 + lsw;
+    const int nt = g.K / BK;
+
+    set_tile(tcur, asrc, wsrc, m0, n0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) stage_piece(asrc, wsrc, 0, j, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();                     // stagger the lower wave group by one interval
+
+    int par = 0;
+    for (;;) {
+        const int tnext = tcur + nper;
+        const bool has_next = tnext < xcnt;
+        if (has_next) set_tile(tnext, nasrc, nwsrc, nm0, nn0);
+
+        f32x4_t acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+        bf16x8_t af[4], wf[4];
+        for (int t = 0; t < nt; ++t) {
+            const char* s = smem + ((par + t) & 1) * STAGE_BYTES;
+            const bool last = (t == nt - 1);
+            const bool more = !last || has_next;
+            const int nbuf = (par + t + 1) & 1;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int kh = p >> 1, mh = p & 1;
+                const char* sp = s + kh * (2 * PIECE_BYTES);
+                if (mh == 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) wf[j] = *(const bf16x8_t*)(sp + w_lane + j * 1024);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8_t*)(sp + a_lane + (mh * 4 + i) * 1024);
+                if (more) {
+                    if (!last) stage_piece(asrc, wsrc, nbuf, p, (t + 1) * BK);
+                    else stage_piece(nasrc, nwsrc, nbuf, p, 0);
+                }
+                if (p & 1) {
+                    // K-tile 0 of every tile was fully waited for (prologue / previous epilogue): no wait at t == 0, p == 1
+                    if (more) { if (t > 0 || p == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+                    else if (p == 1 && t > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[mh * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[mh * 4 + i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (wm == 0) __builtin_amdgcn_s_barrier();                 // re-align: every wave is past its last COMPUTE segment
+        char* ep = smem + ((par + nt - 1) & 1) * STAGE_BYTES + wave * 8192;
+        epilogue_2pass<EPI>(g, acc, ep, m0, n0, wave, lane, has_next, false);
+        if (!has_next) break;
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();                               // next K-tile 0 visible to all; epilogue image is dead
+        if (wm == 1) __builtin_amdgcn_s_barrier();                  // re-stagger
+        par = (par + nt) & 1;
+        asrc[0] = nasrc[0]; asrc[1] = nasrc[1]; wsrc[0] = nwsrc[0]; wsrc[1] = nwsrc[1];
+        m0 = nm0; n0 = nn0;
+        tcur = tnext;
+    }
+}
+
+int num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0)
+            n = p.multiProcessorCount;
+        else
+            n = 256;
+    }
+    return n;
+}
+
+int gemm_variant() {       // 0 = persistent ping-pong (default), 1 = v1 two-stage, 2 = non-persistent ping-pong
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("OVHIP_GEMM_VARIANT");
+        v = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 0;
+    }
+    return v;
+}
+
+template <int EPI>
 int launch(const GemmArgs& a, hipStream_t st) {
     const int nwg = a.tiles_m * a.tiles_n;
-    hipLaunchKernelGGL(gemm_bf16_256x256<EPI>, dim3(nwg), dim3(NTHREADS), 0, st, a);
+    const int var = gemm_variant();
+    if (var == 1) {
+        hipLaunchKernelGGL(gemm_bf16_256x256<EPI>, dim3(nwg), dim3(NTHREADS), 0, st, a);
+    } else if (var == 2) {
+        hipLaunchKernelGGL(gemm_bf16_pp<EPI>, dim3(nwg), dim3(NTHREADS), 0, st, a);
+    } else {
+        const int ncu = num_cus();
+        hipLaunchKernelGGL(gemm_bf16_persist<EPI>, dim3(nwg < ncu ? nwg : ncu), dim3(NTHREADS), 0, st, a);
+    }
     OV_LAUNCH_CHECK();
     return OV_OK;
 }

@@ -215,7 +215,7 @@ extern "C" int ov_tower_forward(const ov_tower* t, ov_bf16* x, int B, int L, voi
                                                     stream))))
             return rc;
         if ((rc = OV_PROF(OV_PROF_LN, ov_layernorm(x, OV_BF16, D, w.ln2_w, w.ln2_b, h, OV_BF16, D, M, D, c.ln_eps, stream)))) return rc;
-        if ((rc = OV_PROF(OV_PROF_GEMM_FC, ov_gemm(h, D, w.fc_w, D, w.fc_b, big, c.mlp_pad, M, c.mlp_pad, D, gelu, nullptr, 0, 0, 0, 0,
+        if ((rc = OV_PROF(c.gelu_tanh ? OV_PROF_GEMM_FC_TANH : OV_PROF_GEMM_FC, ov_gemm(h, D, w.fc_w, D, w.fc_b, big, c.mlp_pad, M, c.mlp_pad, D, gelu, nullptr, 0, 0, 0, 0,
                                                    stream))))
             return rc;
         if ((rc = OV_PROF(OV_PROF_GEMM_PROJ, ov_gemm(big, c.mlp_pad, w.proj_w, c.mlp_pad, w.proj_b, x, D, M, D, c.mlp_pad,
