@@ -40,7 +40,8 @@ __device__ __forceinline__ bf16x8_t tr_pair(const char* p0, const char* p1) {
     return __builtin_bit_cast(bf16x8_t, c);
 }
 
-__global__ __launch_bounds__(1024) void attn_fwd_hd64(const AttnArgs a) {
+// <= 96 VGPRs: 5 waves per SIMD, so two 9-wave workgroups (L = 257) are co-resident per CU (LDS 2 x 72 KiB)
+__global__ __launch_bounds__(576, 5) void attn_fwd_hd64(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, nthreads = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nw = nthreads >> 6;
@@ -104,9 +105,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_hd64(const AttnArgs a) {
                 const bf16x8_t kf = *(const bf16x8_t*)(kp + (((2 * st + h2) ^ k_sw) << 4));
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], s, 0, 0, 0);
             }
-            // s[i] <-> key kt*32 + (i&3) + 8*(i>>2) + 4*h2, query r
-#pragma unroll
-            for (int i = 0; i < 16; ++i) s[i] *= a.scale_log2;
+            // s[i] <-> key kt*32 + (i&3) + 8*(i>>2) + 4*h2, query r   (raw q.k; the softmax scale rides in the exp2 FMA)
             if (kt * 32 + 32 > nk) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
@@ -114,22 +113,27 @@ __global__ __launch_bounds__(1024) void attn_fwd_hd64(const AttnArgs a) {
                     if (key >= nk) s[i] = -INFINITY;
                 }
             }
-            float mx = s[0];
+            float mx = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
+            mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(s[8], s[9]), fmaxf(s[10], s[11])), fmaxf(fmaxf(s[12], s[13]), fmaxf(s[14], s[15]))));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * a.scale_log2;
+            // deferred rescale (bpt.py:108-124 recurrence, rescale only when the running max grows by more than 2^8):
+            // P stays <= 2^8, exact in fp32 sums and scale-free in bf16; wave-uniform branch.
+            if (!__all(mx - m <= 8.0f)) {
+                const float mn = fmaxf(m, mx);
+                const float alpha = __builtin_amdgcn_exp2f(m - mn);
+                m = mn;
+                lsum *= alpha;
 #pragma unroll
-            for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s[i]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float mn = fmaxf(m, mx);
-            const float alpha = __builtin_amdgcn_exp2f(m - mn);
-            m = mn;
+                for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+            }
+            const float nm = -m;
             float ps = 0.f;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                s[i] = __builtin_amdgcn_exp2f(s[i] - mn);
+                s[i] = __builtin_amdgcn_exp2f(fmaf(s[i], a.scale_log2, nm));
                 ps += s[i];
             }
-            lsum = lsum * alpha + ps;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+            lsum += ps;
             // ---- P^T as the B operand of the two k-steps ----
             bf16x8_t pf[2];
 #pragma unroll

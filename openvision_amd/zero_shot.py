@@ -1,0 +1,93 @@
+"""Counterpart of the fork's ``ov-zero-shot-test.py`` on the MI355X path.
+
+    python -m openvision_amd.zero_shot --use_model DIR --image_dir testcat --tokens prompts.npy [--labels a,b,c]
+
+Reproduces the script's observable behaviour: config-dir loading (:37-56), the printed visual-config block (:59-65),
+the per-image sorted cosine / probability table (:167-195) and the per-text best image (:198-208).  Differences, both
+outside the hot path: the HF tokenizer needs the hub (``ov-zero-shot-test.py:81``), so prompts are given as an int64
+``[n, context_length]`` ``.npy`` of token ids; image resize/normalise uses PIL + numpy instead of torchvision.
+``DIR`` holds ``open_clip_config.json`` and either ``open_clip_pytorch_model.bin`` (loaded with
+``torch.load(weights_only=True)``) or, with ``--synthetic``, formula weights.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import config as ovcfg
+from . import synth
+from .model import create_model, logits
+
+
+def load_images(image_dir: str, size: int, mean: Sequence[float], std: Sequence[float]) -> Tuple[List[str], torch.Tensor]:
+    from PIL import Image
+    names = [n for n in sorted(os.listdir(image_dir)) if n.lower().endswith((".png", ".jpg", ".jpeg", ".webp"))]
+    out = []
+    for n in names:
+        im = Image.open(os.path.join(image_dir, n)).convert("RGB").resize((size, size), Image.BILINEAR)
+        a = (np.asarray(im, dtype=np.float32) / 255.0 - np.asarray(mean, np.float32)) / np.asarray(std, np.float32)
+        out.append(a.transpose(2, 0, 1))
+    return names, torch.from_numpy(np.stack(out))
+
+
+def describe(model) -> str:
+    v = model.visual
+    return ("\nVisual Config Used:\n"
+            f"  Pool type:             {v.pool_type}\n"
+            f"  Final LN after pool:   {v.final_ln_after_pool}\n"
+            f"  Attn pool:             {v.attn_pool}\n"
+            f"  Projection shape:      {tuple(v.proj.shape)}\n"
+            f"  Positional emb shape:  {tuple(v.positional_embedding.shape)}\n"
+            f"  Class token shape:     {tuple(v.class_embedding.shape)}\n")
+
+
+@torch.no_grad()
+def zero_shot_table(model, images: torch.Tensor, tokens: torch.Tensor):
+    """cosine [n_img, n_txt], probs, argsort(desc) — images are encoded one at a time, as the script does."""
+    tf = model.encode_text(tokens, normalize=True)
+    rows = [logits(model.encode_image(images[i:i + 1], normalize=True), tf)[0] for i in range(images.shape[0])]
+    cos = torch.stack(rows)
+    scale = float(model.logit_scale.detach().exp())
+    probs = torch.softmax(cos * scale, dim=-1)       # [n_img, n_txt] softmax: plumbing on a 5x9 table
+    return cos, probs, cos.argsort(dim=-1, descending=True)
+
+
+def main(argv: Optional[Sequence[str]] = None) -> int:
+    ap = argparse.ArgumentParser(description="OpenVision Text-Image Test (MI355X)")
+    ap.add_argument("--use_model", required=True)
+    ap.add_argument("--image_dir", default="testcat")
+    ap.add_argument("--tokens", required=True, help=".npy int64 [n, context_length] token ids")
+    ap.add_argument("--labels", default="")
+    ap.add_argument("--synthetic", action="store_true", help="formula weights instead of open_clip_pytorch_model.bin")
+    a = ap.parse_args(argv)
+    model_cfg, pp = ovcfg.load_config_dir(a.use_model)
+    if a.synthetic:
+        sd = synth.make_state_dict(model_cfg)
+    else:
+        sd = torch.load(os.path.join(a.use_model, "open_clip_pytorch_model.bin"), map_location="cpu", weights_only=True)
+    model = create_model({k: v for k, v in model_cfg.items() if k in ("embed_dim", "vision_cfg", "text_cfg")},
+                         device="cuda:0", state_dict=sd)
+    print(describe(model))
+    names, imgs = load_images(a.image_dir, model_cfg["vision_cfg"]["image_size"], pp["mean"], pp["std"])
+    tokens = torch.from_numpy(np.load(a.tokens, allow_pickle=False).astype(np.int64))
+    labels = a.labels.split(",") if a.labels else [f"prompt {i}" for i in range(tokens.shape[0])]
+    cos, probs, order = zero_shot_table(model, imgs.to("cuda:0"), tokens.to("cuda:0"))
+    cos, probs, order = cos.cpu(), probs.cpu(), order.cpu()
+    print("\n=== Cosine Similarities and Predictions ===")
+    for i, n in enumerate(names):
+        print(f"\n--- {n} ---")
+        for j in order[i].tolist():
+            print(f"{labels[j]:<25} cosine: {cos[i, j]:+.4f}  prob: {probs[i, j]:.4%}")
+    print("\n=== Best Image Per Text ===")
+    best = probs.argmax(dim=0)
+    for j, lab in enumerate(labels):
+        print(f"{lab:<20} <- {names[int(best[j])]:>25} ({probs[int(best[j]), j]:.4%})")
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

@@ -1,0 +1,52 @@
+"""CPU: the C-ABI library loads and exports every symbol include/ovhip.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+
+from openvision_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "ovhip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ov_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported_and_bound():
+    syms = declared_symbols()
+    assert len(syms) >= 25
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/ovhip.h but not exported by libovhip.so"
+        assert s in _lib.SIGNATURES, f"{s} has no ctypes signature in openvision_amd/_lib.py"
+    assert sorted(_lib.SIGNATURES) == syms
+
+
+def test_library_loads_and_reports_missing_device_cleanly():
+    lib = _lib.load()
+    assert lib.ov_abi_version() == 1
+    assert lib.ov_error_string(0) == b"ok"
+    assert lib.ov_error_string(-2).startswith(b"shape")
+    import torch
+    if not torch.cuda.is_available():
+        rc = lib.ov_device_check()
+        assert rc < 0 and lib.ov_error_string(rc)          # an error code, not a crash
+
+
+def test_argument_validation_without_gpu():
+    lib = _lib.load()
+    # null pointers / bad sizes are rejected before any HIP call
+    assert lib.ov_gemm(None, 64, None, 64, None, None, 64, 1, 8, 64, 0, None, 0, 0, 0, 0, None) == -1
+    assert lib.ov_layernorm(None, 1, 8, None, None, None, 1, 8, 1, 8, 1e-6, None) == -1
+    assert lib.ov_clip_loss_workspace_bytes(256, 2048) > 0
+    assert lib.ov_tower_create(None) is None
+    cfg = _lib.TowerCfg(192, 2, 3, 768, 768, 0, 1e-6)
+    t = lib.ov_tower_create(ctypes.byref(cfg))
+    assert t
+    assert lib.ov_tower_workspace_bytes(t, 4, 101) >= 4 * 101 * (192 + 768) * 2
+    assert lib.ov_tower_forward(t, None, 4, 101, None, 0, None) == -1
+    lib.ov_tower_destroy(t)
+    bad = _lib.TowerCfg(100, 2, 3, 400, 400, 0, 1e-6)        # width not a multiple of 64
+    assert lib.ov_tower_create(ctypes.byref(bad)) is None

@@ -1,0 +1,60 @@
+"""CPU, world_size 2 over gloo: the N>1 host path — rank-ordered all-gather of packed [b, 2E] embeddings
+(openvision_amd.loss.gather_features), label offsets b*rank, and the data-parallel batch sharding bench.py uses.
+The loss arithmetic itself is HIP-only (no CPU fallback), so the oracle stands in as the checker here."""
+import os
+import tempfile
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import golden
+
+
+def _worker(rank, ws, store, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    dist.init_process_group("gloo", init_method=f"file://{store}", rank=rank, world_size=ws)
+    from openvision_amd.loss import gather_features, ClipLoss
+    from oracle import clip_ref as R
+    g = golden("cliploss_ws.npz")
+    img, txt, s = torch.from_numpy(g["img"]), torch.from_numpy(g["txt"]), torch.from_numpy(g["scale"])
+    b = img.shape[0] // ws
+    li, lt = img[rank * b:(rank + 1) * b].contiguous(), txt[rank * b:(rank + 1) * b].contiguous()
+    ai, at = gather_features(li, lt, local_loss=True, rank=rank, world_size=ws)
+    ok_order = bool(torch.equal(ai, img) and torch.equal(at, txt))          # rank order == torch.cat(gathered)
+    loss = float(R.clip_loss(li, lt, s, ai, at, rank))                        # labels i + b*rank
+    try:                                                                      # product loss on CPU tensors must refuse
+        ClipLoss(local_loss=True, rank=rank, world_size=ws)(li, lt, s)
+        refused = False
+    except RuntimeError:
+        refused = True
+    q.put((rank, ok_order, loss, refused))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_and_local_loss_world_size_2():
+    ws = 2
+    ctx = mp.get_context("spawn")
+    with tempfile.TemporaryDirectory() as d:
+        q = ctx.Queue()
+        ps = [ctx.Process(target=_worker, args=(r, ws, os.path.join(d, "store"), q)) for r in range(ws)]
+        [p.start() for p in ps]
+        res = sorted(q.get(timeout=300) for _ in range(ws))
+        [p.join(60) for p in ps]
+    g = golden("cliploss_ws.npz")
+    for rank, ok_order, loss, refused in res:
+        assert ok_order and refused
+        assert abs(loss - float(g["local_losses_ws2"][rank])) < 1e-6       # == the reference's per-rank ClipLoss
+    assert abs(np.mean([r[2] for r in res]) - float(g["loss_ws1"])) < 1e-6
+
+
+def test_gather_requires_process_group():
+    from openvision_amd.loss import gather_features
+    import pytest
+    with pytest.raises(RuntimeError):
+        gather_features(torch.zeros(2, 8), torch.zeros(2, 8), world_size=2)
+    a, b = gather_features(torch.ones(2, 8), torch.zeros(2, 8), world_size=1)
+    assert a.shape == (2, 8)

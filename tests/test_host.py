@@ -1,0 +1,115 @@
+"""CPU: host-side logic of the drop-in surface (config, state-dict contract, packing, error behaviour)."""
+import json
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from openvision_amd import config as ovcfg, synth, preset
+from openvision_amd.model import CLIP, create_model, _pack_matrix
+from openvision_amd.loss import ClipLoss
+from openvision_amd._lib import OvhipError
+
+
+def test_presets_match_reference_size_table():
+    c = preset("vit-large-patch14-224")
+    assert c["embed_dim"] == 768 and c["vision_cfg"]["width"] == 1024 and c["vision_cfg"]["layers"] == 24
+    assert c["text_cfg"]["width"] == 768 and c["text_cfg"]["heads"] == 12 and c["text_cfg"]["context_length"] == 80
+    t = preset("vit-tiny-patch16-160")
+    assert (t["vision_cfg"]["image_size"], t["vision_cfg"]["patch_size"], t["embed_dim"]) == (160, 16, 192)
+    assert ovcfg.mlp_width(1152, 3.7362) == 4304                       # So400m (transfer_jax2hf.py:81)
+
+
+def test_flop_model_matches_survey():
+    f = synth.model_flops(preset("vit-large-patch14-224"))
+    assert abs(f["image"] / 1e9 - 162.03) < 0.02 and abs(f["text"] / 1e9 - 13.83) < 0.01
+    assert abs(f["pair"] / 1e9 - 175.85) < 0.02
+    s = synth.model_flops(preset("vit-small-patch8-384"))
+    assert abs(s["image"] / 1e9 - 196.16) < 0.05
+
+
+def test_unsupported_configs_fail_loudly():
+    c = preset("vit-tiny-patch16-160")
+    with pytest.raises(ValueError):
+        ovcfg.vision_cfg_from({**c["vision_cfg"], "attentional_pool": True})
+    with pytest.raises(ValueError):
+        ovcfg.text_cfg_from({**c["text_cfg"], "no_causal_mask": False})
+    with pytest.raises(ValueError):
+        ovcfg.vision_cfg_from({**c["vision_cfg"], "timm_model_name": "vit_base"})
+    with pytest.raises(NotImplementedError):
+        CLIP(192, c["vision_cfg"], c["text_cfg"], quick_gelu=True)
+
+
+def test_state_dict_contract_and_attribute_tree():
+    cfg = preset("vit-tiny-patch16-160")
+    sd = synth.make_state_dict(cfg)
+    m = create_model(cfg, state_dict=sd)                      # strict load, as ov-zero-shot-test.py:54
+    msd = m.state_dict()
+    assert set(msd) == set(sd) and len(sd) == 300
+    for k in sd:
+        assert tuple(msd[k].shape) == tuple(sd[k].shape), k
+        assert torch.equal(msd[k], sd[k])
+    assert "visual.ln_pre.weight" not in msd and "visual.conv1.bias" not in msd and "attn_mask" not in msd
+    v = m.visual                                               # attributes the scripts print / walk (:59-65, :105-153)
+    assert v.pool_type == "avg" and v.final_ln_after_pool and v.attn_pool is None
+    assert v.proj.shape == (192, 192) and v.positional_embedding.shape == (101, 192) and v.class_embedding.shape == (192,)
+    assert isinstance(v.ln_pre, torch.nn.Identity) and isinstance(v.patch_dropout, torch.nn.Identity)
+    assert v.image_size == (160, 160) and v.grid_size == (10, 10)
+    assert m.transformer.get_cast_dtype() == torch.float32
+    assert m.visual.transformer.resblocks[0].mlp.c_proj.in_features == 768      # ov-feature-visualization.py:151-155
+    assert m.attn_mask is None and m.context_length == 80 and m.vocab_size == 32000 and m.text_pool_type == "last"
+    assert abs(float(m.logit_scale) - math.log(1 / 0.07)) < 1e-6
+    assert m.visual.transformer.resblocks[0].mlp.gelu.approximate == "none"
+    assert m.transformer.resblocks[0].mlp.gelu.approximate == "tanh"
+    m2 = m.float().eval()
+    assert m2 is m
+    with pytest.raises(RuntimeError):
+        m.load_state_dict({**sd, "visual.ln_pre.weight": torch.ones(192)}, strict=True)
+
+
+def test_no_cpu_fallback_anywhere():
+    cfg = preset("vit-tiny-patch16-160")
+    m = create_model(cfg)
+    with pytest.raises(OvhipError):
+        m.encode_image(torch.zeros(1, 3, 160, 160))
+    with pytest.raises(OvhipError):
+        m.encode_text(torch.zeros(1, 80, dtype=torch.long))
+    with pytest.raises(OvhipError):
+        m.visual.transformer(torch.zeros(1, 101, 192))
+    with pytest.raises(OvhipError):
+        m.visual.ln_post(torch.zeros(2, 192))
+    with pytest.raises(OvhipError):
+        m.visual.conv1(torch.zeros(1, 3, 160, 160))
+    with pytest.raises(OvhipError):
+        ClipLoss()(torch.zeros(2, 8), torch.zeros(2, 8), torch.tensor(1.0))
+    with pytest.raises(NotImplementedError):
+        ClipLoss(use_horovod=True)
+
+
+def test_packing_pads_with_zeros():
+    w = torch.arange(12, dtype=torch.float32).view(3, 4)
+    p = _pack_matrix(w, 8, 64)
+    assert p.shape == (8, 64) and p.dtype == torch.bfloat16
+    assert torch.equal(p[:3, :4].float(), w) and float(p[3:].abs().sum()) == 0 and float(p[:, 4:].abs().sum()) == 0
+
+
+def test_synth_is_deterministic_and_caption_format():
+    a = synth.make_state_dict(preset("vit-tiny-patch16-160"), seed=0)["visual.conv1.weight"]
+    b = synth.make_state_dict(preset("vit-tiny-patch16-160"), seed=0)["visual.conv1.weight"]
+    assert torch.equal(a, b)
+    t = synth.make_captions(16, 80, 32000, seed=3)
+    assert t.dtype == torch.int64 and t.shape == (16, 80)
+    assert (t[:, 0] == 1).all() and (t[:, 79] == 101).all()           # [bos ... eos pad.. cls@79] (bert_ops.py:496-507)
+    for row in t:
+        eos = (row == 2).nonzero()[0, 0].item()
+        assert 5 <= eos <= 61 and (row[eos + 1:79] == 0).all() and (row[1:eos] >= 1000).all()
+    pe = synth.posemb_sincos_2d(10, 10, 192)
+    assert pe.shape == (101, 192) and float(pe[0].abs().sum()) == 0    # cls row zeros (transfer_jax2hf.py:108-109)
+
+
+def test_config_dir_roundtrip(tmp_path):
+    cfg = preset("vit-tiny-patch16-160")
+    (tmp_path / "open_clip_config.json").write_text(json.dumps({"model_cfg": cfg, "preprocess_cfg": ovcfg.DEFAULT_PREPROCESS}))
+    mc, pp = ovcfg.load_config_dir(str(tmp_path))
+    assert mc == cfg and pp["mean"][0] == pytest.approx(0.48145466)
