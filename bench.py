@@ -136,8 +136,8 @@ def main():
         loss = step()
     fence()
     dt = time.perf_counter() - t0
-    tot, cnt = C.c_double(0), C.c_int(0)
-    _lib.check(lib.ov_profile_read(PROF_CLASSES["gemm_fc"], C.byref(tot), C.byref(cnt)), "ov_profile_read")
+    tot, cnt, rows = C.c_double(0), C.c_int(0), C.c_double(0)
+    _lib.check(lib.ov_profile_read(PROF_CLASSES["gemm_fc"], C.byref(tot), C.byref(cnt), C.byref(rows)), "ov_profile_read")
     _lib.check(lib.ov_profile_enable(0, 0), "ov_profile_enable")
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -157,7 +157,7 @@ def main():
         breakdown = {"step_ms": round(e0.elapsed_time(e1), 3)}
         for name, cid in PROF_CLASSES.items():
             t_, c_ = C.c_double(0), C.c_int(0)
-            _lib.check(lib.ov_profile_read(cid, C.byref(t_), C.byref(c_)), "prof read")
+            _lib.check(lib.ov_profile_read(cid, C.byref(t_), C.byref(c_), None), "prof read")
             breakdown[name] = {"ms": round(t_.value, 3), "launches": c_.value}
         _lib.check(lib.ov_profile_enable(0, 0), "prof off")
 
@@ -167,8 +167,9 @@ def main():
         # dominant kernel: gemm_bf16_256x256<GELU> (c_fc).  Algorithmic FLOP per launch = 2*M*N*K.
         g = S // cfg["vision_cfg"]["patch_size"]
         Lv, Dv, Dt = g * g + 1, cfg["vision_cfg"]["width"], cfg["text_cfg"]["width"]
-        flop_per_launch = 2.0 * b * Lv * Dv * int(Dv * cfg["vision_cfg"]["mlp_ratio"])
         launches = max(cnt.value, 1)
+        # M of the timed launches comes from the library (the tower may peel tail images onto a side stream)
+        flop_per_launch = 2.0 * (rows.value / launches) * Dv * int(Dv * cfg["vision_cfg"]["mlp_ratio"])
         avg_ms = tot.value / launches
         achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         traffic = None

@@ -137,13 +137,14 @@ int ov_clip_loss(const float* img, const float* txt, const float* all_img, const
 /* ---- in-situ kernel timing (used by bench.py for the roofline object; off by default) ------------------
  * ov_profile_enable(mask, n): bracket every launch of the selected classes inside ov_tower_forward with a pair
  * of HIP events recorded on the launch stream (n = max launches recorded; resets earlier records; mask 0 = off).
- * ov_profile_read(cls, &ms, &count): synchronises the recorded events and returns the summed device time. */
+ * ov_profile_read(cls, &ms, &count, &rows): synchronises the recorded events and returns the summed device time and
+ * the summed row count M of those launches (launches on the internal tail stream are not recorded). */
 enum ov_profile_class {
     OV_PROF_LN = 0, OV_PROF_GEMM_QKV = 1, OV_PROF_ATTN = 2, OV_PROF_GEMM_OUT = 3, OV_PROF_GEMM_FC = 4 /* erf-GELU c_fc (vision) */, OV_PROF_GEMM_PROJ = 5,
     OV_PROF_GEMM_FC_TANH = 6 /* tanh-GELU c_fc (text) */
 };
 int ov_profile_enable(unsigned class_mask, int max_records);
-int ov_profile_read(int cls, double* total_ms, int* count);
+int ov_profile_read(int cls, double* total_ms, int* count, double* total_rows /* sum of launch M, may be NULL */);
 
 /* ---- tower level (the resblock loop and the two encoders) --------------------------------------- */
 

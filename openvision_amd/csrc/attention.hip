@@ -20,6 +20,7 @@
 //   P^T = exp2(S^T - m)    packed pairwise to bf16: the accumulator tile IS the next B operand
 //   O^T += V^T . P^T       (V^T fragments via the transposing LDS read)
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -28,9 +29,12 @@ struct AttnArgs {
     ov_bf16* out; int64_t ldo;
     int B, L, H, nqt, KC;
     float scale_log2;
+    int mode;      // diagnostics only (OVHIP_ATTN_MODE): 0 = full, 1 = staging only, 2 = compute only
 };
 
 typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
 
 __device__ __forceinline__ bf16x8_t tr_pair(const char* p0, const char* p1) {
     const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)p0);
@@ -78,22 +82,37 @@ __global__ __launch_bounds__(576, 5) void attn_fwd_hd64(const AttnArgs a) {
 
     for (int kc0 = 0; kc0 < L; kc0 += KC) {
         if (kc0) __syncthreads();
-        // ---- stage K and V rows [kc0, kc0+KC) of this (batch, head) ----
-        for (int idx = tid; idx < KC * 8; idx += nthreads) {
-            const int row = idx >> 3, c = idx & 7;
-            u32x4_t kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
-            if (kc0 + row < L) {
-                const ov_bf16* p = base + (int64_t)(kc0 + row) * a.ldq + HD + c * 8;
-                kv = *(const u32x4_t*)p;
-                vv = *(const u32x4_t*)(p + HD);
+        // ---- stage K and V rows [kc0, kc0+KC) of this (batch, head): LDS-DMA, every piece in flight at once ----
+        // LDS 16-B chunk q of the K image holds key q>>3, d-chunk (q&7) ^ ((key>>1)&7); chunk q of V half dh holds key q>>2,
+        // d-chunk dh*4 + (q&3).  The DMA writes LDS lane-linearly, so the permutation sits on the per-lane SOURCE address.
+        // Keys >= L are clamped to L-1: finite data (their scores are masked to -inf, their P is exactly 0).
+        {
+            const int nchunk = KC * 8;                                   // per image (K) and for both V halves together
+            for (int q0c = wave * 64; q0c < nchunk && a.mode != 2; q0c += nthreads) {   // wave-uniform trip count (64 | KC*8)
+                const int q = q0c + lane;
+                {
+                    const int key = q >> 3;
+                    int row = kc0 + key;
+                    row = row < L ? row : L - 1;
+                    const int c = (q & 7) ^ ((key >> 1) & 7);
+                    __builtin_amdgcn_global_load_lds((gptr_t)(base + (int64_t)row * a.ldq + HD + c * 8), (lptr_t)(ks + q0c * 16),
+                                                     16, 0, 0);
+                }
+                {
+                    const int dh = q0c >= KC * 4 ? 1 : 0;                // wave-uniform (64 | KC*4)
+                    const int qq = q - dh * KC * 4;
+                    int row = kc0 + (qq >> 2);
+                    row = row < L ? row : L - 1;
+                    __builtin_amdgcn_global_load_lds((gptr_t)(base + (int64_t)row * a.ldq + 2 * HD + (dh * 4 + (qq & 3)) * 8),
+                                                     (lptr_t)(vs + q0c * 16), 16, 0, 0);
+                }
             }
-            *(u32x4_t*)(ks + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = kv;
-            *(u32x4_t*)(vs + (c >> 2) * (KC * 64) + row * 64 + (c & 3) * 16) = vv;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
         if (!active) continue;
         const int nk = (L - kc0) < KC ? (L - kc0) : KC;
-        const int ntile = (nk + 31) >> 5;
+        const int ntile = a.mode == 1 ? 0 : (nk + 31) >> 5;
         for (int kt = 0; kt < ntile; ++kt) {
             // ---- S^T = K . Q^T ----
             f32x16_t s;
@@ -172,6 +191,295 @@ __global__ __launch_bounds__(576, 5) void attn_fwd_hd64(const AttnArgs a) {
     }
 }
 
+// =====================================================================================================
+// Persistent variant (default when two heads' K/V fit in LDS, i.e. padded L <= 320): a workgroup of nqt waves (one per
+// 32-row query tile) walks heads bh = blockIdx.x, blockIdx.x + gridDim.x, ...  K/V of head j live in LDS slot j & 1.
+// Per head: vmcnt(0) + ONE barrier (head j has landed for everybody, and everybody has left head j-1), then the LDS-DMA
+// of head j+1 into the other slot is issued and runs under the MFMAs/softmax of head j -- HBM reads overlap compute.
+// The kernel is sized for <= 168 VGPRs (3 waves on the busiest SIMD at L = 257), which leaves room to fetch all K and V
+// fragments of a key tile ahead of the MFMAs that use them.
+// Transposing LDS reads issued from inline asm: hipcc treats the ds_read_tr builtin as possibly aliasing the LDS-DMA
+// (global_load_lds) writes of the NEXT head and would drain them with vmcnt(0) before every V read, serialising the
+// prefetch.  The asm forms are invisible to its memory model; completion is enforced by tr_wait(), which names every
+// destination "+v" (cdna guide 5.7 form ii) so no consumer can be scheduled above the lgkmcnt wait.
+__device__ __forceinline__ u32x2_t tr_read_asm(const char* p) {
+    u32x2_t v;
+    const unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+__device__ __forceinline__ void tr_wait(u32x2_t (&t)[8]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]));
+}
+__device__ __forceinline__ bf16x8_t tr_join(u32x2_t a, u32x2_t b) {
+    const u32x4_t w = {a[0], a[1], b[0], b[1]};
+    return __builtin_bit_cast(bf16x8_t, w);
+}
+
+struct AttnPArgs {
+    const ov_bf16* qkv; int64_t ldq;
+    ov_bf16* out; int64_t ldo;
+    int L, H, nqt, KC, nheads;
+    float scale_log2;
+};
+
+__device__ __forceinline__ void stage_head(const AttnPArgs& a, int bh, char* slot, int wave, int lane, int nthreads) {
+    const int b = bh / a.H, h = bh - b * a.H;
+    const int HD = a.H * 64, KC = a.KC, L = a.L;
+    const ov_bf16* base = a.qkv + (int64_t)b * L * a.ldq + h * 64;
+    char* ks = slot;
+    char* vs = slot + KC * 128;
+    const int nchunk = KC * 8;
+    for (int q0c = wave * 64; q0c < nchunk; q0c += nthreads) {
+        const int q = q0c + lane;
+        {
+            const int key = q >> 3;
+            const int row = key < L ? key : L - 1;
+            const int c = (q & 7) ^ ((key >> 1) & 7);
+            __builtin_amdgcn_global_load_lds((gptr_t)(base + (int64_t)row * a.ldq + HD + c * 8), (lptr_t)(ks + q0c * 16), 16, 0, 0);
+        }
+        {
+            const int dh = q0c >= KC * 4 ? 1 : 0;
+            const int qq = q - dh * KC * 4;
+            const int key = qq >> 2;
+            const int row = key < L ? key : L - 1;
+            __builtin_amdgcn_global_load_lds((gptr_t)(base + (int64_t)row * a.ldq + 2 * HD + (dh * 4 + (qq & 3)) * 8),
+                                             (lptr_t)(vs + q0c * 16), 16, 0, 0);
+        }
+    }
+}
+
+__device__ __forceinline__ float max3_asm(float x, float y, float z) {       // no canonicalising v_max in front
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(y), "v"(z));
+    return d;
+}
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+// p = exp2(s * c - m) on 16 scores, two per v_pk_fma_f32 / v_pk_add_f32 (the softmax is VALU-issue bound; v_exp has no
+// packed form); acc collects the two interleaved partial row sums.
+__device__ __forceinline__ void exp_rows(f32x16_t& s, float c, float nm, f32x2_t& acc) {
+    const f32x2_t cc = {c, c}, mm = {nm, nm};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        f32x2_t v = {s[2 * i], s[2 * i + 1]};
+        v = __builtin_elementwise_fma(v, cc, mm);
+        v[0] = __builtin_amdgcn_exp2f(v[0]);
+        v[1] = __builtin_amdgcn_exp2f(v[1]);
+        acc += v;
+        s[2 * i] = v[0];
+        s[2 * i + 1] = v[1];
+    }
+}
+template <int OFF>
+__device__ __forceinline__ u32x2_t tr_read_off(unsigned addr) {
+    u32x2_t v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+
+__global__ __launch_bounds__(640, 3) void attn_fwd_hd64_persist(const AttnPArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h2 = lane >> 5;
+    const int L = a.L, KC = a.KC;
+    const int slot_bytes = KC * 256;
+    const int nk_tiles = (L + 31) >> 5;
+    const int n = (a.nheads - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;     // heads of this workgroup
+    if (n <= 0) return;
+
+    const int k_lane = r * 128;
+    const int k_sw = (r >> 1) & 7;
+    int ksw[4];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) ksw[st] = k_lane + (((2 * st + h2) ^ k_sw) << 4);
+    const int vi = lane & 15, vg = (lane >> 4) & 1;
+    const int v_lane0 = KC * 128 + (4 * h2 + (vi >> 2)) * 64 + (16 * vg + 4 * (vi & 3)) * 2;   // d half 0
+    const int v_lane1 = v_lane0 + KC * 64;                                                    // d half 1
+    const int q0 = wave * 32;
+    int qrow = q0 + r;
+    qrow = qrow < L ? qrow : L - 1;
+
+    auto head_base = [&](int bh) {
+        const int b = bh / a.H, h = bh - b * a.H;
+        return a.qkv + (int64_t)b * L * a.ldq + h * 64;
+    };
+    // VM-op order per head and wave: [LDS-DMA pieces of head j+1][4 Q loads of head j+1][8 output stores of head j].
+    // The wait in front of head j+1 is vmcnt(8): everything but the 8 youngest operations (the stores) has completed,
+    // so stores drain under the next head's MFMAs.  That count is exact because the 8 stores are never predicated:
+    // lanes past the last query replicate query L-1 (qrow clamp) and rewrite its row with identical values.
+    auto load_q = [&](u32x4_t (&q)[4], int bh) {
+        const ov_bf16* qp = head_base(bh) + (int64_t)qrow * a.ldq + 8 * h2;
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(q[st]) : "v"(qp + 16 * st) : "memory");
+    };
+    stage_head(a, blockIdx.x, smem, wave, lane, blockDim.x);
+    u32x4_t qn[4];
+    load_q(qn, blockIdx.x);
+
+    for (int j = 0; j < n; ++j) {
+        const int bh = blockIdx.x + j * gridDim.x;
+        if (j == 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(qn[0]), "+v"(qn[1]), "+v"(qn[2]), "+v"(qn[3]) :: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" : "+v"(qn[0]), "+v"(qn[1]), "+v"(qn[2]), "+v"(qn[3]) :: "memory");
+        bf16x8_t qf[4];
+#pragma unroll
+        for (int st = 0; st < 4; ++st) qf[st] = __builtin_bit_cast(bf16x8_t, qn[st]);
+        __builtin_amdgcn_s_barrier();   // raw barrier (a __syncthreads fence would drain vmcnt to 0, stores included):
+                                        // everybody's pieces have landed and everybody has left head j-1
+        if (j + 1 < n) stage_head(a, bh + gridDim.x, smem + ((j + 1) & 1) * slot_bytes, wave, lane, blockDim.x);
+        const char* ks = smem + (j & 1) * slot_bytes;
+        const unsigned ks_u = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)ks;
+
+        float m = -INFINITY, lsum = 0.f;
+        f32x16_t o0, o1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
+        // Key tiles are consumed two at a time (64 keys: two independent S accumulators, one max / rescale decision,
+        // 32 exps) with the K fragments of the NEXT step fetched right behind the S MFMAs, so LDS latency and the
+        // MFMA->VALU->MFMA dependency chain of one tile are covered by the other's work; an odd last tile runs alone.
+        bf16x8_t kfa[4], kfb[4];
+        auto load_k = [&](bf16x8_t (&kf)[4], int kt) {
+            const char* kp = ks + kt * 4096;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) kf[st] = *(const bf16x8_t*)(kp + ksw[st]);
+        };
+        auto mask_tail = [&](f32x16_t& sc, int kt) {
+            if (kt * 32 + 32 > L) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = kt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h2;
+                    if (key >= L) sc[i] = -INFINITY;
+                }
+            }
+        };
+        auto tile_max = [&](const f32x16_t& sc) {
+            float mx = max3_asm(max3_asm(sc[0], sc[1], sc[2]), max3_asm(sc[3], sc[4], sc[5]), max3_asm(sc[6], sc[7], sc[8]));
+            return max3_asm(mx, max3_asm(sc[9], sc[10], sc[11]), max3_asm(max3_asm(sc[12], sc[13], sc[14]), sc[15], sc[15]));
+        };
+        auto pack_p = [&](const f32x16_t& sc, int st) {
+            const u32x4_t w = {pack_bf16x2(sc[8 * st + 0], sc[8 * st + 1]), pack_bf16x2(sc[8 * st + 2], sc[8 * st + 3]),
+                               pack_bf16x2(sc[8 * st + 4], sc[8 * st + 5]), pack_bf16x2(sc[8 * st + 6], sc[8 * st + 7])};
+            return __builtin_bit_cast(bf16x8_t, w);
+        };
+        const int npair = nk_tiles >> 1;
+        load_k(kfa, 0);
+        for (int it = 0; it < npair; ++it) {
+            const int kt = 2 * it;
+            const unsigned va0 = ks_u + kt * 2048 + v_lane0, va1 = ks_u + kt * 2048 + v_lane1;
+            load_k(kfb, kt + 1);                                       // second tile's K: covered by the first tile's MFMAs
+            u32x2_t vt[8], vu[8];
+            vt[0] = tr_read_off<0>(va0);    vt[1] = tr_read_off<512>(va0);
+            vt[2] = tr_read_off<0>(va1);    vt[3] = tr_read_off<512>(va1);
+            vt[4] = tr_read_off<1024>(va0); vt[5] = tr_read_off<1536>(va0);
+            vt[6] = tr_read_off<1024>(va1); vt[7] = tr_read_off<1536>(va1);
+            f32x16_t sa, sb;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { sa[i] = 0.f; sb[i] = 0.f; }
+#pragma unroll
+            for (int st = 0; st < 4; ++st) sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfa[st], qf[st], sa, 0, 0, 0);
+#pragma unroll
+            for (int st = 0; st < 4; ++st) sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfb[st], qf[st], sb, 0, 0, 0);
+            if (kt + 2 < nk_tiles) load_k(kfa, kt + 2);                // next step's first tile, fetched under the softmax
+            mask_tail(sb, kt + 1);
+            float mx = fmaxf(tile_max(sa), tile_max(sb));
+            {
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+                mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])) * a.scale_log2;
+            }
+            if (!__all(mx - m <= 8.0f)) {
+                const float mn = fmaxf(m, mx);
+                const float alpha = __builtin_amdgcn_exp2f(m - mn);
+                m = mn;
+                lsum *= alpha;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+            }
+            const float nm = -m;
+            f32x2_t ps = {0.f, 0.f};
+            exp_rows(sa, a.scale_log2, nm, ps);
+            exp_rows(sb, a.scale_log2, nm, ps);
+            lsum += ps[0] + ps[1];
+            const bf16x8_t pa0 = pack_p(sa, 0), pa1 = pack_p(sa, 1), pb0 = pack_p(sb, 0), pb1 = pack_p(sb, 1);
+            tr_wait(vt);
+            __builtin_amdgcn_sched_barrier(0);
+            // second tile's V fragments: their LDS latency hides under the first tile's four P.V MFMAs
+            vu[0] = tr_read_off<2048>(va0); vu[1] = tr_read_off<2560>(va0);
+            vu[2] = tr_read_off<2048>(va1); vu[3] = tr_read_off<2560>(va1);
+            vu[4] = tr_read_off<3072>(va0); vu[5] = tr_read_off<3584>(va0);
+            vu[6] = tr_read_off<3072>(va1); vu[7] = tr_read_off<3584>(va1);
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join(vt[0], vt[1]), pa0, o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join(vt[2], vt[3]), pa0, o1, 0, 0, 0);
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join(vt[4], vt[5]), pa1, o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join(vt[6], vt[7]), pa1, o1, 0, 0, 0);
+            tr_wait(vu);
+            __builtin_amdgcn_sched_barrier(0);
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join(vu[0], vu[1]), pb0, o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join(vu[2], vu[3]), pb0, o1, 0, 0, 0);
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join(vu[4], vu[5]), pb1, o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join(vu[6], vu[7]), pb1, o1, 0, 0, 0);
+        }
+        if (j + 1 < n) load_q(qn, bh + gridDim.x);                   // next head's Q rows, live only across the tail step
+        if (nk_tiles & 1) {
+            const int kt = nk_tiles - 1;
+            const unsigned va0 = ks_u + kt * 2048 + v_lane0, va1 = ks_u + kt * 2048 + v_lane1;
+            u32x2_t vt[8];
+            vt[0] = tr_read_off<0>(va0);    vt[1] = tr_read_off<512>(va0);
+            vt[2] = tr_read_off<0>(va1);    vt[3] = tr_read_off<512>(va1);
+            vt[4] = tr_read_off<1024>(va0); vt[5] = tr_read_off<1536>(va0);
+            vt[6] = tr_read_off<1024>(va1); vt[7] = tr_read_off<1536>(va1);
+            f32x16_t sa;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sa[i] = 0.f;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfa[st], qf[st], sa, 0, 0, 0);
+            mask_tail(sa, kt);
+            float mx = tile_max(sa);
+            {
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+                mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])) * a.scale_log2;
+            }
+            if (!__all(mx - m <= 8.0f)) {
+                const float mn = fmaxf(m, mx);
+                const float alpha = __builtin_amdgcn_exp2f(m - mn);
+                m = mn;
+                lsum *= alpha;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+            }
+            const float nm = -m;
+            f32x2_t ps = {0.f, 0.f};
+            exp_rows(sa, a.scale_log2, nm, ps);
+            lsum += ps[0] + ps[1];
+            const bf16x8_t pa0 = pack_p(sa, 0), pa1 = pack_p(sa, 1);
+            tr_wait(vt);
+            __builtin_amdgcn_sched_barrier(0);
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join(vt[0], vt[1]), pa0, o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join(vt[2], vt[3]), pa0, o1, 0, 0, 0);
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join(vt[4], vt[5]), pa1, o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join(vt[6], vt[7]), pa1, o1, 0, 0, 0);
+        }
+        float l;
+        {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lsum), __float_as_uint(lsum), false, false);
+            l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        }
+        const float inv = 1.0f / l;
+        ov_bf16* op = a.out + ((int64_t)(bh / a.H) * L + qrow) * a.ldo + (bh % a.H) * 64 + 4 * h2;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const u32x2_t w0 = {pack_bf16x2(o0[4 * gq] * inv, o0[4 * gq + 1] * inv),
+                                pack_bf16x2(o0[4 * gq + 2] * inv, o0[4 * gq + 3] * inv)};
+            const u32x2_t w1 = {pack_bf16x2(o1[4 * gq] * inv, o1[4 * gq + 1] * inv),
+                                pack_bf16x2(o1[4 * gq + 2] * inv, o1[4 * gq + 3] * inv)};
+            asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(op + 8 * gq), "v"(w0) : "memory");
+            asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 0" :: "v"(op + 32 + 8 * gq), "v"(w1) : "memory");
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int ov_attention(const ov_bf16* qkv, int64_t ld_qkv, ov_bf16* out, int64_t ld_out, int B, int L,
@@ -185,7 +493,39 @@ extern "C" int ov_attention(const ov_bf16* qkv, int64_t ld_qkv, ov_bf16* out, in
     a.B = B; a.L = L; a.H = H;
     a.nqt = (L + 31) / 32;
     a.scale_log2 = scale * 1.4426950408889634f;
+    { static int mode = -1; if (mode < 0) { const char* e = getenv("OVHIP_ATTN_MODE"); mode = e ? atoi(e) : 0; } a.mode = mode; }
     const int lp = a.nqt * 32;
+    static int force_v1 = -1;
+    if (force_v1 < 0) { const char* e = getenv("OVHIP_ATTN_V1"); force_v1 = (e && e[0] == '1') ? 1 : 0; }
+    if (lp <= 320 && !force_v1) {
+        AttnPArgs p;
+        p.qkv = qkv; p.ldq = ld_qkv; p.out = out; p.ldo = ld_out;
+        p.L = L; p.H = H; p.nqt = a.nqt; p.KC = lp; p.nheads = B * H; p.scale_log2 = a.scale_log2;
+        static bool attr2 = false;
+        if (!attr2) {
+            hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_hd64_persist, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               160 * 1024);
+            if (e != hipSuccess) return OV_ERR_HIP - (int)e;
+            attr2 = true;
+        }
+        static int ncu = 0;
+        if (ncu == 0) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+                   prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        }
+        const size_t smem = (size_t)2 * lp * 256;
+        int per_cu = (int)((160 * 1024) / smem);                  // workgroups per CU by LDS ...
+        const int by_waves = 12 / a.nqt;                          // ... and by waves (<= 3 per SIMD at <= 168 VGPRs)
+        if (per_cu > by_waves) per_cu = by_waves;
+        if (per_cu < 1) per_cu = 1;
+        const int cap = ncu * per_cu;
+        const int grid = p.nheads < cap ? p.nheads : cap;
+        hipLaunchKernelGGL(attn_fwd_hd64_persist, dim3((unsigned)grid), dim3(a.nqt * 64), smem, (hipStream_t)stream, p);
+        OV_LAUNCH_CHECK();
+        return OV_OK;
+    }
     int nw;
     if (lp <= 320) { a.KC = lp; nw = a.nqt; }          // whole K/V of a head resident: one chunk
     else { a.KC = 256; nw = 8; }

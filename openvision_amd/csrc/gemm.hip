@@ -542,7 +542,9 @@ int gemm_variant() {       // 0 = persistent ping-pong (default), 1 = v1 two-sta
 template <int EPI>
 int launch(const GemmArgs& a, hipStream_t st) {
     const int nwg = a.tiles_m * a.tiles_n;
-    const int var = gemm_variant();
+    int var = gemm_variant();
+    // fewer tiles than CUs (pooled heads, the tower's tail images): persistence buys nothing, use the plain launch
+    if (var == 0 && nwg < num_cus()) var = 2;
     if (var == 1) {
         hipLaunchKernelGGL(gemm_bf16_256x256<EPI>, dim3(nwg), dim3(NTHREADS), 0, st, a);
     } else if (var == 2) {

@@ -14,6 +14,7 @@
 #include <new>
 #include <vector>
 #include <mutex>
+#include <stdlib.h>
 
 struct ov_tower {
     ov_tower_cfg cfg;
@@ -23,7 +24,7 @@ struct ov_tower {
 
 namespace {
 // ---- optional in-situ kernel timing (HIP events on the caller's stream; off by default) -----------------
-struct ProfRec { int cls; hipEvent_t e0, e1; };
+struct ProfRec { int cls; hipEvent_t e0, e1; int64_t rows; };
 struct Profiler {
     std::mutex mu;
     unsigned mask = 0;
@@ -35,8 +36,9 @@ struct ProfScope {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     hipStream_t st;
     int cls;
+    int64_t rows;
     bool on = false;
-    ProfScope(int c, ov_stream_t s) : st((hipStream_t)s), cls(c) {
+    ProfScope(int c, ov_stream_t s, int64_t r) : st((hipStream_t)s), cls(c), rows(r) {
         if (!(g_prof.mask & (1u << c))) return;
         std::lock_guard<std::mutex> lk(g_prof.mu);
         if (g_prof.pool.size() < 2) return;
@@ -49,10 +51,9 @@ struct ProfScope {
         if (!on) return;
         (void)hipEventRecord(e1, st);
         std::lock_guard<std::mutex> lk(g_prof.mu);
-        g_prof.recs.push_back({cls, e0, e1});
+        g_prof.recs.push_back({cls, e0, e1, rows});
     }
 };
-#define OV_PROF(cls, call) [&]() { ProfScope ps__(cls, stream); return (call); }()
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 inline int max_i(int a, int b) { return a > b ? a : b; }
@@ -133,10 +134,10 @@ extern "C" int ov_profile_enable(unsigned class_mask, int max_records) {
     return OV_OK;
 }
 
-extern "C" int ov_profile_read(int cls, double* total_ms, int* count) {
+extern "C" int ov_profile_read(int cls, double* total_ms, int* count, double* total_rows) {
     if (!total_ms || !count) return OV_ERR_INVALID;
     std::lock_guard<std::mutex> lk(g_prof.mu);
-    double tot = 0.0;
+    double tot = 0.0, rows = 0.0;
     int n = 0;
     for (auto& r : g_prof.recs) {
         if (r.cls != cls) continue;
@@ -146,10 +147,12 @@ extern "C" int ov_profile_read(int cls, double* total_ms, int* count) {
         err = hipEventElapsedTime(&ms, r.e0, r.e1);
         if (err != hipSuccess) return OV_ERR_HIP - (int)err;
         tot += ms;
+        rows += (double)r.rows;
         ++n;
     }
     *total_ms = tot;
     *count = n;
+    if (total_rows) *total_rows = rows;
     return OV_OK;
 }
 
@@ -190,37 +193,116 @@ extern "C" size_t ov_tower_workspace_bytes(const ov_tower* t, int B, int L) {
     return align_up(M * D * 2, 256) + align_up(M * (size_t)max_i(3 * D, t->cfg.mlp_pad) * 2, 256);
 }
 
+namespace {
+// One ResidualAttentionBlock on rows [0, B*L) of x (in place).  `prof` = record in-situ timings for these launches.
+int run_block(const ov_tower_cfg& c, const ov_block_weights& w, ov_bf16* x, ov_bf16* h, ov_bf16* big, int B, int L,
+              ov_stream_t stream, bool prof) {
+    const int D = c.width, H = c.heads, hd = D / H;
+    const int64_t M = (int64_t)B * L;
+    const int ldb = 3 * D > c.mlp_pad ? 3 * D : c.mlp_pad;      // row pitch of `big` (shared by qkv and the MLP hidden)
+    const float scale = 1.0f / sqrtf((float)hd);
+    const int gelu = c.gelu_tanh ? OV_EPI_BIAS_GELU_TANH : OV_EPI_BIAS_GELU_ERF;
+    const int fc_cls = c.gelu_tanh ? OV_PROF_GEMM_FC_TANH : OV_PROF_GEMM_FC;
+    int rc;
+#define OV_STEP(cls, call)                                           \
+    do {                                                             \
+        if (prof) { ProfScope ps__(cls, stream, M); rc = (call); }   \
+        else rc = (call);                                            \
+        if (rc) return rc;                                           \
+    } while (0)
+    OV_STEP(OV_PROF_LN, ov_layernorm(x, OV_BF16, D, w.ln1_w, w.ln1_b, h, OV_BF16, D, M, D, c.ln_eps, stream));
+    OV_STEP(OV_PROF_GEMM_QKV, ov_gemm(h, D, w.qkv_w, D, w.qkv_b, big, ldb, M, 3 * D, D, OV_EPI_BIAS, nullptr, 0, 0, 0, 0, stream));
+    OV_STEP(OV_PROF_ATTN, ov_attention(big, ldb, h, D, B, L, H, hd, scale, stream));
+    OV_STEP(OV_PROF_GEMM_OUT, ov_gemm(h, D, w.out_w, D, w.out_b, x, D, M, D, D, OV_EPI_BIAS_RESIDUAL, x, D, 0, 0, 0, stream));
+    OV_STEP(OV_PROF_LN, ov_layernorm(x, OV_BF16, D, w.ln2_w, w.ln2_b, h, OV_BF16, D, M, D, c.ln_eps, stream));
+    OV_STEP(fc_cls, ov_gemm(h, D, w.fc_w, D, w.fc_b, big, ldb, M, c.mlp_pad, D, gelu, nullptr, 0, 0, 0, 0, stream));
+    OV_STEP(OV_PROF_GEMM_PROJ, ov_gemm(big, ldb, w.proj_w, c.mlp_pad, w.proj_b, x, D, M, D, c.mlp_pad, OV_EPI_BIAS_RESIDUAL, x,
+                                       D, 0, 0, 0, stream));
+#undef OV_STEP
+    return OV_OK;
+}
+
+// Side stream for the "tail" images of a batch (tile-quantisation fix, see ov_tower_forward).
+struct TailCtx {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    int state = 0;                         // 0 = not created, 1 = ok, -1 = unavailable
+};
+TailCtx g_tail;
+std::mutex g_tail_mu;
+
+TailCtx* tail_ctx() {
+    std::lock_guard<std::mutex> lk(g_tail_mu);
+    if (g_tail.state == 0) {
+        const char* e = getenv("OVHIP_NO_TAIL_SPLIT");
+        if (e && e[0] == '1') { g_tail.state = -1; return nullptr; }
+        if (hipStreamCreateWithFlags(&g_tail.stream, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreateWithFlags(&g_tail.fork, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&g_tail.join, hipEventDisableTiming) == hipSuccess)
+            g_tail.state = 1;
+        else
+            g_tail.state = -1;
+    }
+    return g_tail.state == 1 ? &g_tail : nullptr;
+}
+
+// Images to peel off so that the main part's 256-row tile count is a multiple of 64 (x 4 column tiles = whole rounds of
+// 256 CUs for the N = width GEMMs).  0 = do not split.
+int tail_images(int B, int L) {
+    const int64_t T = ((int64_t)B * L + 255) / 256;
+    const int r = (int)(T % 64);
+    if (T <= 64 || r == 0 || r > 8) return 0;
+    const int64_t target = T - r;                                // tiles the main part may use
+    int Bm = (int)((target * 256) / L);                           // largest B' with ceil(B'*L/256) <= target
+    while (Bm > 0 && ((int64_t)Bm * L + 255) / 256 > target) --Bm;
+    const int tail = B - Bm;
+    if (Bm <= 0 || tail <= 0 || tail > B / 8) return 0;
+    return tail;
+}
+}  // namespace
+
+// x[B*L, D] is updated in place through all blocks.  When B*L leaves a few 256-row tiles over a whole number of rounds
+// (L/14 at B = 256: 257 tiles -> the out-proj / c_proj GEMMs need a 5th round for 4 of their 1028 tiles), the last
+// image(s) are peeled off and run, layer by layer, on an internal side stream: rows are independent through LN/GEMM and
+// attention never crosses images, so the split is exact; the main part then fills whole rounds and the tail's small
+// kernels slot into idle CUs.  Fork/join by events; everything remains ordered with respect to the caller's stream.
 extern "C" int ov_tower_forward(const ov_tower* t, ov_bf16* x, int B, int L, void* workspace, size_t workspace_bytes,
                                 ov_stream_t stream) {
     if (!t || !x || !workspace || B <= 0 || L <= 0) return OV_ERR_INVALID;
     if (workspace_bytes < ov_tower_workspace_bytes(t, B, L)) return OV_ERR_WORKSPACE;
     if (((uintptr_t)x | (uintptr_t)workspace) & 15) return OV_ERR_INVALID;
     const ov_tower_cfg& c = t->cfg;
-    const int D = c.width, H = c.heads, hd = D / H;
+    const int D = c.width;
     const int64_t M = (int64_t)B * L;
+    const int ldb = 3 * D > c.mlp_pad ? 3 * D : c.mlp_pad;
     ov_bf16* h = (ov_bf16*)workspace;
     ov_bf16* big = (ov_bf16*)((char*)workspace + align_up((size_t)M * D * 2, 256));
-    const float scale = 1.0f / sqrtf((float)hd);
-    const int gelu = c.gelu_tanh ? OV_EPI_BIAS_GELU_TANH : OV_EPI_BIAS_GELU_ERF;
-    for (int i = 0; i < c.layers; ++i) {
+    for (int i = 0; i < c.layers; ++i)
         if (!t->set[i]) return OV_ERR_INVALID;
-        const ov_block_weights& w = t->blocks[i];
-        int rc;
-        if ((rc = OV_PROF(OV_PROF_LN, ov_layernorm(x, OV_BF16, D, w.ln1_w, w.ln1_b, h, OV_BF16, D, M, D, c.ln_eps, stream)))) return rc;
-        if ((rc = OV_PROF(OV_PROF_GEMM_QKV, ov_gemm(h, D, w.qkv_w, D, w.qkv_b, big, 3 * D, M, 3 * D, D, OV_EPI_BIAS, nullptr, 0, 0, 0,
-                                                    0, stream))))
-            return rc;
-        if ((rc = OV_PROF(OV_PROF_ATTN, ov_attention(big, 3 * D, h, D, B, L, H, hd, scale, stream)))) return rc;
-        if ((rc = OV_PROF(OV_PROF_GEMM_OUT, ov_gemm(h, D, w.out_w, D, w.out_b, x, D, M, D, D, OV_EPI_BIAS_RESIDUAL, x, D, 0, 0, 0,
-                                                    stream))))
-            return rc;
-        if ((rc = OV_PROF(OV_PROF_LN, ov_layernorm(x, OV_BF16, D, w.ln2_w, w.ln2_b, h, OV_BF16, D, M, D, c.ln_eps, stream)))) return rc;
-        if ((rc = OV_PROF(c.gelu_tanh ? OV_PROF_GEMM_FC_TANH : OV_PROF_GEMM_FC, ov_gemm(h, D, w.fc_w, D, w.fc_b, big, c.mlp_pad, M, c.mlp_pad, D, gelu, nullptr, 0, 0, 0, 0,
-                                                   stream))))
-            return rc;
-        if ((rc = OV_PROF(OV_PROF_GEMM_PROJ, ov_gemm(big, c.mlp_pad, w.proj_w, c.mlp_pad, w.proj_b, x, D, M, D, c.mlp_pad,
-                                                     OV_EPI_BIAS_RESIDUAL, x, D, 0, 0, 0, stream))))
-            return rc;
+
+    int nt = tail_images(B, L);
+    TailCtx* tc = nt > 0 ? tail_ctx() : nullptr;
+    if (!tc) nt = 0;
+    const int Bm = B - nt;
+    hipStream_t main_st = (hipStream_t)stream;
+    if (nt > 0) {
+        hipError_t e = hipEventRecord(tc->fork, main_st);
+        if (e == hipSuccess) e = hipStreamWaitEvent(tc->stream, tc->fork, 0);
+        if (e != hipSuccess) return OV_ERR_HIP - (int)e;
+    }
+    const int64_t off = (int64_t)Bm * L;
+    for (int i = 0; i < c.layers; ++i) {
+        int rc = run_block(c, t->blocks[i], x, h, big, Bm, L, stream, true);
+        if (rc) return rc;
+        if (nt > 0) {
+            rc = run_block(c, t->blocks[i], x + off * D, h + off * D, big + off * ldb, nt, L, (ov_stream_t)tc->stream, false);
+            if (rc) return rc;
+        }
+    }
+    if (nt > 0) {
+        hipError_t e = hipEventRecord(tc->join, tc->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(main_st, tc->join, 0);
+        if (e != hipSuccess) return OV_ERR_HIP - (int)e;
     }
     return OV_OK;
 }
