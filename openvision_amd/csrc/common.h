@@ -72,3 +72,29 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
     const float u = 0.7978845608028654f * x * fmaf(0.044715f * x, x, 1.0f);
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * u));
 }
+
+// ---- two-lane (v_pk_*_f32) forms: the GEMM epilogues are VALU-issue bound, packed fp32 halves the instruction count ----
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x2_t gelu_erf_f2(f32x2_t x) {
+    const f32x2_t ax = __builtin_elementwise_abs(x);
+    const f32x2_t z = ax * 0.70710678118654752440f;
+    const f32x2_t d = __builtin_elementwise_fma(z, f32x2_t{0.3275911f, 0.3275911f}, f32x2_t{1.0f, 1.0f});
+    const f32x2_t t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    f32x2_t p = __builtin_elementwise_fma(t, f32x2_t{1.061405429f, 1.061405429f}, f32x2_t{-1.453152027f, -1.453152027f});
+    p = __builtin_elementwise_fma(t, p, f32x2_t{1.421413741f, 1.421413741f});
+    p = __builtin_elementwise_fma(t, p, f32x2_t{-0.284496736f, -0.284496736f});
+    p = __builtin_elementwise_fma(t, p, f32x2_t{0.254829592f, 0.254829592f});
+    p = p * t;
+    const f32x2_t e = z * z * -1.4426950408889634f;
+    const f32x2_t ee = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+    // erf(|x|/sqrt2) = 1 - p*ee ;  gelu = x/2 (1 + sign(x) erf) = x/2 + |x|/2 * erf(|x|/sqrt2)   (branch-free, all packed)
+    const f32x2_t erf_abs = __builtin_elementwise_fma(-p, ee, f32x2_t{1.0f, 1.0f});
+    return __builtin_elementwise_fma(ax * 0.5f, erf_abs, x * 0.5f);
+}
+__device__ __forceinline__ f32x2_t gelu_tanh_f2(f32x2_t x) {
+    const f32x2_t u = x * 0.7978845608028654f * __builtin_elementwise_fma(x * 0.044715f, x, f32x2_t{1.0f, 1.0f});
+    const f32x2_t a = u * -2.8853900817779268f;
+    const f32x2_t den = f32x2_t{__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])} + 1.0f;
+    return x * f32x2_t{__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+}

@@ -30,6 +30,8 @@ struct GemmArgs {
     const ov_bf16* A; const ov_bf16* W; const float* bias; ov_bf16* C; const ov_bf16* R;
     int64_t lda, ldw, ldc, ldr, M;
     int N, K, tiles_m, tiles_n, out_group, resid_mod, resid_off;
+    unsigned long long* stamps;     // diagnostics only (ov_debug_gemm_stamps): [block][tile slot][4] s_memtime values
+    int stamp_slots;
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -59,15 +61,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4_t (&acc)[
         const int ml = i * 16 + fr;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float x = acc[i][j][r] + bv[j][r];
-                if (EPI == OV_EPI_BIAS_GELU_ERF) x = gelu_erf_f(x);
-                if (EPI == OV_EPI_BIAS_GELU_TANH) x = gelu_tanh_f(x);
-                v[r] = x;
-            }
-            u32x2_t p = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            // same arithmetic (packed fp32) as epilogue_2pass: results must not depend on which kernel variant ran
+            f32x2_t v01 = f32x2_t{acc[i][j][0], acc[i][j][1]} + f32x2_t{bv[j][0], bv[j][1]};
+            f32x2_t v23 = f32x2_t{acc[i][j][2], acc[i][j][3]} + f32x2_t{bv[j][2], bv[j][3]};
+            if (EPI == OV_EPI_BIAS_GELU_ERF) { v01 = gelu_erf_f2(v01); v23 = gelu_erf_f2(v23); }
+            if (EPI == OV_EPI_BIAS_GELU_TANH) { v01 = gelu_tanh_f2(v01); v23 = gelu_tanh_f2(v23); }
+            u32x2_t p = {pack_bf16x2(v01[0], v01[1]), pack_bf16x2(v23[0], v23[1])};
             const int c = j * 2 + (fq >> 1);
             *(u32x2_t*)(ep + ml * 128 + ((c ^ (ml & 7)) << 4) + (fq & 1) * 8) = p;
         }
@@ -335,15 +334,11 @@ __device__ __forceinline__ void epilogue_2pass(const GemmArgs& g, f32x4_t (&acc)
             const int ml = i * 16 + fr;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float x = acc[h * 4 + i][j][r] + bv[j][r];
-                    if (EPI == OV_EPI_BIAS_GELU_ERF) x = gelu_erf_f(x);
-                    if (EPI == OV_EPI_BIAS_GELU_TANH) x = gelu_tanh_f(x);
-                    v[r] = x;
-                }
-                u32x2_t pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                f32x2_t v01 = f32x2_t{acc[h * 4 + i][j][0], acc[h * 4 + i][j][1]} + f32x2_t{bv[j][0], bv[j][1]};
+                f32x2_t v23 = f32x2_t{acc[h * 4 + i][j][2], acc[h * 4 + i][j][3]} + f32x2_t{bv[j][2], bv[j][3]};
+                if (EPI == OV_EPI_BIAS_GELU_ERF) { v01 = gelu_erf_f2(v01); v23 = gelu_erf_f2(v23); }
+                if (EPI == OV_EPI_BIAS_GELU_TANH) { v01 = gelu_tanh_f2(v01); v23 = gelu_tanh_f2(v23); }
+                u32x2_t pk = {pack_bf16x2(v01[0], v01[1]), pack_bf16x2(v23[0], v23[1])};
                 const int c = j * 2 + (fq >> 1);
                 *(u32x2_t*)(ep + ml * 128 + ((c ^ (ml & 7)) << 4) + (fq & 1) * 8) = pk;
             }
@@ -385,7 +380,7 @@ __device__ __forceinline__ void epilogue_2pass(const GemmArgs& g, f32x4_t (&acc)
 
 template <int EPI>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist(const GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
+    __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES + 2048];   // + 256 B per wave: dump for the residual prefetch
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -443,6 +438,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist(const GemmArgs 
     const int a_lane = (wm * 128 + fr) * 64 + lsw;
     const int w_lane = PIECE_BYTES + (wn * 64 + fr) * 64 + lsw;
     const int nt = g.K / BK;
+    // Residual epilogue: every CU would read its 128-KiB residual tile in one burst right behind its last MFMA, all CUs at
+    // once (HBM-latency bound, ~12 us per tile).  Three K-tiles ahead each thread touches its 2 of the tile's 1024 lines
+    // with a 4-byte LDS-DMA into a dump area, so the epilogue's 16-byte reads hit L2 / Infinity Cache instead.
+    const int pf_t = (EPI == OV_EPI_BIAS_RESIDUAL && g.resid_mod == 0 && nt >= 4) ? nt - 3 : -1;
 
     set_tile(tcur, asrc, wsrc, m0, n0);
 #pragma unroll
@@ -452,7 +451,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist(const GemmArgs 
     if (wm == 1) __builtin_amdgcn_s_barrier();                     // stagger the lower wave group by one interval
 
     int par = 0;
+    int titer = 0;
+    auto stamp = [&](int k) {
+        if (g.stamps != nullptr && tid == 0 && titer < g.stamp_slots)
+            g.stamps[((size_t)bid * g.stamp_slots + titer) * 4 + k] = __builtin_amdgcn_s_memtime();
+    };
     for (;;) {
+        stamp(0);
         const int tnext = tcur + nper;
         const bool has_next = tnext < xcnt;
         if (has_next) set_tile(tnext, nasrc, nwsrc, nm0, nn0);
@@ -485,8 +490,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist(const GemmArgs 
                 }
                 if (p & 1) {
                     // K-tile 0 of every tile was fully waited for (prologue / previous epilogue): no wait at t == 0, p == 1
-                    if (more) { if (t > 0 || p == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
-                    else if (p == 1 && t > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (more) {
+                        if (p == 1 && t == pf_t + 1 && pf_t >= 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // + 2 prefetches
+                        else if (t > 0 || p == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    } else if (p == 1 && t > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (EPI == OV_EPI_BIAS_RESIDUAL && p == 3 && t == pf_t) {
+                        int64_t pr = m0 + (tid >> 1);
+                        pr = pr < g.M ? pr : g.M - 1;
+                        const ov_bf16* rp = g.R + pr * g.ldr;
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            int pc = n0 + ((tid & 1) * 2 + i) * 64;
+                            pc = pc < g.N ? pc : g.N - 2;
+                            __builtin_amdgcn_global_load_lds((gptr_t)(rp + pc), (lptr_t)(smem + SMEM_BYTES + wave * 256), 4, 0, 0);
+                        }
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
@@ -503,9 +521,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist(const GemmArgs 
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        stamp(1);
         if (wm == 0) __builtin_amdgcn_s_barrier();                 // re-align: every wave is past its last COMPUTE segment
+        stamp(2);
         char* ep = smem + ((par + nt - 1) & 1) * STAGE_BYTES + wave * 8192;
         epilogue_2pass<EPI>(g, acc, ep, m0, n0, wave, lane, has_next, false);
+        stamp(3);
+        ++titer;
         if (!has_next) break;
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();                               // next K-tile 0 visible to all; epilogue image is dead
@@ -529,6 +551,9 @@ int num_cus() {
     }
     return n;
 }
+
+unsigned long long* g_stamps = nullptr;
+int g_stamp_slots = 0;
 
 int gemm_variant() {       // 0 = persistent ping-pong (default), 1 = v1 two-stage, 2 = non-persistent ping-pong
     static int v = -1;
@@ -576,7 +601,7 @@ extern "C" int ov_gemm(const ov_bf16* A, int64_t lda, const ov_bf16* W, int64_t 
     const int64_t tiles_n = (N + BN - 1) / BN;
     if (tiles_m * tiles_n > 0x7fffffffLL) return OV_ERR_UNSUPPORTED;
     GemmArgs a{A, W, bias, C, R, lda, ldw, ldc, ldr, M, N, K, (int)tiles_m, (int)tiles_n,
-               out_group, resid_mod, resid_off};
+               out_group, resid_mod, resid_off, g_stamps, g_stamp_slots};
     hipStream_t st = (hipStream_t)stream;
     switch (epilogue) {
         case OV_EPI_BIAS: return launch<OV_EPI_BIAS>(a, st);
@@ -585,4 +610,12 @@ extern "C" int ov_gemm(const ov_bf16* A, int64_t lda, const ov_bf16* W, int64_t 
         case OV_EPI_BIAS_RESIDUAL: return launch<OV_EPI_BIAS_RESIDUAL>(a, st);
         default: return OV_ERR_INVALID;
     }
+}
+
+// Diagnostics: when set, the persistent kernel's thread 0 of every workgroup records s_memtime at tile start / main-loop
+// end / after the re-align barrier / epilogue end into buf[block][slot][4] (slot = tile iteration < slots).  NULL = off.
+extern "C" int ov_debug_gemm_stamps(unsigned long long* buf, int slots) {
+    g_stamps = buf;
+    g_stamp_slots = buf ? slots : 0;
+    return OV_OK;
 }

@@ -1,0 +1,37 @@
+"""Diagnostic: per-tile timeline of the persistent GEMM (s_memtime stamps; 100 MHz constant clock on gfx950)."""
+import os, sys, torch, numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import hipops as H
+from openvision_amd import _lib
+lib = _lib.load()
+M = 65535
+cases = {"qkv": (3072, 1024, 0), "out": (1024, 1024, 3), "fc": (4096, 1024, 1), "proj": (1024, 4096, 3)}
+for name, (N, K, epi) in cases.items():
+    a = torch.randn(M, K, device="cuda").to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda") / K ** 0.5).to(torch.bfloat16)
+    bias = torch.randn(N, device="cuda")
+    x = torch.randn(M, N, device="cuda").to(torch.bfloat16)
+    out = x.clone() if epi == 3 else torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    for _ in range(3):
+        H.gemm(a, w, bias, epi=epi, resid=out if epi == 3 else None, out=out)
+    slots = 20
+    buf = torch.zeros(256 * slots * 4, dtype=torch.int64, device="cuda")
+    lib.ov_debug_gemm_stamps(_lib.ptr(buf), slots)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); H.gemm(a, w, bias, epi=epi, resid=out if epi == 3 else None, out=out); e1.record()
+    torch.cuda.synchronize()
+    lib.ov_debug_gemm_stamps(None, 0)
+    st = buf.cpu().numpy().reshape(256, slots, 4).astype(np.float64)
+    ntile = int((st[:, :, 0] > 0).sum(1).max())
+    st = st[:, :ntile]
+    t0 = st[:, 0, 0].min()
+    us = lambda v: v / 100.0          # s_memtime ticks: 100 MHz
+    main = us(st[:, :, 1] - st[:, :, 0]); align = us(st[:, :, 2] - st[:, :, 1]); epi_t = us(st[:, :, 3] - st[:, :, 2])
+    gap = us(st[:, 1:, 0] - st[:, :-1, 3]) if ntile > 1 else np.zeros((256, 1))
+    print(f"{name}: kernel {e0.elapsed_time(e1)*1e3:.1f} us, tiles/CU {ntile}, K-tiles {K//64}: main {main.mean():.2f} us "
+          f"(min {main.min():.2f} max {main.max():.2f}) = {main.mean()/(K//64):.3f} us/K-tile; align {align.mean():.2f}; "
+          f"epilogue {epi_t.mean():.2f} (min {epi_t.min():.2f} max {epi_t.max():.2f}); restart gap {gap.mean():.2f}; "
+          f"first start spread {us(st[:,0,0].max()-t0):.2f}, last end spread {us(st[:,-1,3].max()-st[:,-1,3].min()):.2f}")
+    print("   per-tile main (CU 0):", np.round(main[0], 2), " epilogue (CU 0):", np.round(epi_t[0], 2))
