@@ -310,6 +310,13 @@ __global__ __launch_bounds__(640, 3) void attn_fwd_hd64_persist(const AttnPArgs 
     // The wait in front of head j+1 is vmcnt(8): everything but the 8 youngest operations (the stores) has completed,
     // so stores drain under the next head's MFMAs.  That count is exact because the 8 stores are never predicated:
     // lanes past the last query replicate query L-1 (qrow clamp) and rewrite its row with identical values.
+    // VM-op order per head and wave: [LDS-DMA pieces of head j+1 (top of head j)] ... [4 Q loads of head j+1][8 stores of head j].
+    // The wait is vmcnt(8) at the END of head j, right behind the stores: everything but the 8 youngest operations (the
+    // stores) has completed, so the stores drain under the next head's MFMAs while its K/V pieces (issued a whole head
+    // earlier) and Q rows are known to have landed.  The count is exact because the 8 stores are never predicated (lanes
+    // past the last query replicate query L-1 and rewrite its row with identical values) and are inline asm.
+    // The Q loads are inline asm too (hipcc would drain the LDS-DMA queue at the first use of an ordinary load); the wait
+    // names their registers "+v" in the same basic block, before any loop-carried copy can be made of them.
     auto load_q = [&](u32x4_t (&q)[4], int bh) {
         const ov_bf16* qp = head_base(bh) + (int64_t)qrow * a.ldq + 8 * h2;
 #pragma unroll
@@ -319,15 +326,15 @@ __global__ __launch_bounds__(640, 3) void attn_fwd_hd64_persist(const AttnPArgs 
     stage_head(a, blockIdx.x, smem, wave, lane, blockDim.x);
     u32x4_t qn[4];
     load_q(qn, blockIdx.x);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(qn[0]), "+v"(qn[1]), "+v"(qn[2]), "+v"(qn[3]) :: "memory");
 
     for (int j = 0; j < n; ++j) {
         const int bh = blockIdx.x + j * gridDim.x;
-        if (j == 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(qn[0]), "+v"(qn[1]), "+v"(qn[2]), "+v"(qn[3]) :: "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" : "+v"(qn[0]), "+v"(qn[1]), "+v"(qn[2]), "+v"(qn[3]) :: "memory");
         bf16x8_t qf[4];
 #pragma unroll
         for (int st = 0; st < 4; ++st) qf[st] = __builtin_bit_cast(bf16x8_t, qn[st]);
-        __builtin_amdgcn_s_barrier();   // raw barrier (a __syncthreads fence would drain vmcnt to 0, stores included):
+        asm volatile("s_barrier" ::: "memory");   // raw barrier (a __syncthreads fence would drain vmcnt to 0, stores included);
+                                                  // the memory clobber keeps every LDS read of head j below it:
                                         // everybody's pieces have landed and everybody has left head j-1
         if (j + 1 < n) stage_head(a, bh + gridDim.x, smem + ((j + 1) & 1) * slot_bytes, wave, lane, blockDim.x);
         const char* ks = smem + (j & 1) * slot_bytes;
@@ -477,6 +484,7 @@ __global__ __launch_bounds__(640, 3) void attn_fwd_hd64_persist(const AttnPArgs 
             asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(op + 8 * gq), "v"(w0) : "memory");
             asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 0" :: "v"(op + 32 + 8 * gq), "v"(w1) : "memory");
         }
+        asm volatile("s_waitcnt vmcnt(8)" : "+v"(qn[0]), "+v"(qn[1]), "+v"(qn[2]), "+v"(qn[3]) :: "memory");
     }
 }
 

@@ -116,10 +116,17 @@ def test_large14_224_features():
     ni, nt, s = m(img, tok)
     assert abs(float(ClipLoss()(ni, nt, s)) - float(g["loss"])) < 0.05
     # full-size property checks (config #2 shape, B=256 would need the whole-batch oracle): batch invariance at B=32
-    big = synth.make_images(32, 224, seed=3).to(DEV).to(torch.bfloat16)
+    big = synth.make_images(48, 224, seed=3).to(DEV).to(torch.bfloat16)
     fb = m.encode_image(big)
     assert torch.equal(fb[:7], m.encode_image(big[:7]))
     assert torch.isfinite(fb).all()
+    # bitwise repeatability with several heads per persistent attention workgroup (48*16 heads > 256 CUs) and
+    # persistent GEMM tiles: guards the LDS-DMA double-buffer hand-offs (a real race was caught this way)
+    tb = synth.make_captions(48, seed=3).to(DEV)
+    ft0 = m.encode_text(tb)
+    for _ in range(4):
+        assert torch.equal(fb, m.encode_image(big))
+        assert torch.equal(ft0, m.encode_text(tb))
 
 
 @pytest.mark.timeout(900)
