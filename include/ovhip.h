@@ -7,6 +7,7 @@
  *
  *   ov_layernorm        LayerNorm / LayerNormFp32.forward                     transformer.py:15-30
  *   ov_gemm             nn.Linear (c_fc/c_proj/out_proj/in_proj), `@ proj`    transformer.py:225,232-236,645-646
+ *   ov_rowstats+ov_gemm_ln  ln_1 -> in_proj and ln_2 -> c_fc fused (LN folded into the GEMM epilogue) transformer.py:263-264
  *   ov_attention        nn.MultiheadAttention core (softmax(qk^T/sqrt(hd)) v) transformer.py:239-252
  *   ov_im2col_patches   conv1 (stride = kernel = P) operand gather            transformer.py:469,610-612
  *   ov_cls_rows         class_embedding concat + pos-emb row 0                transformer.py:615-617
@@ -81,6 +82,16 @@ int ov_gemm(const ov_bf16* A, int64_t lda, const ov_bf16* W, int64_t ldw, const 
             ov_bf16* C, int64_t ldc, int64_t M, int N, int K, int epilogue,
             const ov_bf16* R, int64_t ldr, int out_group, int resid_mod, int resid_off,
             ov_stream_t stream);
+
+/* LayerNorm folded into the following Linear (LN(x) W^T + b without materialising LN(x)):
+ *   C = epilogue( rstd[m] * (x W'^T - mean[m] * colsum[n]) + cvec[n] ),
+ *   W'[n,k] = bf16(gamma[k] W[n,k]), colsum[n] = sum_k W'[n,k], cvec[n] = sum_k beta[k] W[n,k] + b[n]   (built once at pack time),
+ *   rowstats[m] = {mean, rstd} of row m of x from ov_rowstats (fp32 [M,2]).  Epilogues BIAS / GELU only. */
+int ov_gemm_ln(const ov_bf16* X, int64_t ldx, const ov_bf16* Wg, int64_t ldw, const float* cvec, const float* colsum,
+               const float* rowstats, ov_bf16* C, int64_t ldc, int64_t M, int N, int K, int epilogue, ov_stream_t stream);
+
+/* rowstats[r] = {mean, rsqrt(var + eps)} of x[r, 0:D] (bf16 rows, fp32 two-pass statistics, biased variance). */
+int ov_rowstats(const ov_bf16* x, int64_t ldx, float* rowstats, int64_t rows, int D, float eps, ov_stream_t stream);
 
 /* Non-causal, unmasked multi-head self-attention on a packed qkv activation.
  * qkv: [B*L, 3*H*hd] bf16 (q | k | v column blocks, heads contiguous inside each, ld = ld_qkv);
@@ -170,6 +181,10 @@ typedef struct {      /* one ResidualAttentionBlock; weights bf16 [out,in] row-m
     const float *ln2_w, *ln2_b;
     const ov_bf16* fc_w;   const float* fc_b;      /* [mlp_pad, D], [mlp_pad] (pad rows = 0) */
     const ov_bf16* proj_w; const float* proj_b;    /* [D, mlp_pad] (pad cols = 0), [D]      */
+    /* Optional LN fold (both NULL = off).  When set, qkv_w / fc_w hold gamma-scaled weights W', qkv_b / fc_b hold cvec, and
+     * these are the column sums of W' (see ov_gemm_ln); ln1_* / ln2_* are then unused by the tower. */
+    const float* qkv_colsum;                       /* [3D]      */
+    const float* fc_colsum;                        /* [mlp_pad] */
 } ov_block_weights;
 
 ov_tower* ov_tower_create(const ov_tower_cfg* cfg);

@@ -25,7 +25,7 @@ class TowerCfg(C.Structure):
 
 class BlockWeights(C.Structure):
     _fields_ = [(n, c_void_p) for n in ("ln1_w", "ln1_b", "qkv_w", "qkv_b", "out_w", "out_b", "ln2_w", "ln2_b",
-                                        "fc_w", "fc_b", "proj_w", "proj_b")]
+                                        "fc_w", "fc_b", "proj_w", "proj_b", "qkv_colsum", "fc_colsum")]
 
 
 class VisionHead(C.Structure):
@@ -50,6 +50,9 @@ SIGNATURES = {
                              c_float, c_void_p]),
     "ov_gemm": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int,
                         c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    "ov_gemm_ln": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int,
+                           c_int, c_int, c_void_p]),
+    "ov_rowstats": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_float, c_void_p]),
     "ov_attention": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "ov_im2col_patches": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "ov_cls_rows": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

@@ -30,6 +30,8 @@ struct GemmArgs {
     const ov_bf16* A; const ov_bf16* W; const float* bias; ov_bf16* C; const ov_bf16* R;
     int64_t lda, ldw, ldc, ldr, M;
     int N, K, tiles_m, tiles_n, out_group, resid_mod, resid_off;
+    const float* colsum;            // LN fold: column sums of W' (NULL = plain GEMM)
+    const float* rowstats;          // LN fold: {mean, rstd} per row of A
     unsigned long long* stamps;     // diagnostics only (ov_debug_gemm_stamps): [block][tile slot][4] s_memtime values
     int stamp_slots;
 };
@@ -56,14 +58,45 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4_t (&acc)[
             bv[j][0] = bv[j][1] = bv[j][2] = bv[j][3] = 0.f;
         }
     }
+    const bool fold = (EPI != OV_EPI_BIAS_RESIDUAL) && g.colsum != nullptr;
+    float sv[4][4];
+    if (fold) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nn = n0 + wn * 64 + j * 16 + fq * 4;
+            if (nn < g.N) {
+                const float4 s4 = *(const float4*)(g.colsum + nn);
+                sv[j][0] = s4.x; sv[j][1] = s4.y; sv[j][2] = s4.z; sv[j][3] = s4.w;
+            } else {
+                sv[j][0] = sv[j][1] = sv[j][2] = sv[j][3] = 0.f;
+            }
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int ml = i * 16 + fr;
+        float rmean = 0.f, rrstd = 1.f;
+        if (fold) {
+            int64_t m = m0 + wm * 128 + i * 16 + fr;
+            m = m < g.M ? m : g.M - 1;
+            const float2 st = *(const float2*)(g.rowstats + 2 * m);
+            rmean = st.x; rrstd = st.y;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             // same arithmetic (packed fp32) as epilogue_2pass: results must not depend on which kernel variant ran
-            f32x2_t v01 = f32x2_t{acc[i][j][0], acc[i][j][1]} + f32x2_t{bv[j][0], bv[j][1]};
-            f32x2_t v23 = f32x2_t{acc[i][j][2], acc[i][j][3]} + f32x2_t{bv[j][2], bv[j][3]};
+            f32x2_t v01 = f32x2_t{acc[i][j][0], acc[i][j][1]};
+            f32x2_t v23 = f32x2_t{acc[i][j][2], acc[i][j][3]};
+            if (fold) {
+                const f32x2_t nm = {-rmean, -rmean}, rs = {rrstd, rrstd};
+                v01 = __builtin_elementwise_fma(f32x2_t{sv[j][0], sv[j][1]}, nm, v01);
+                v23 = __builtin_elementwise_fma(f32x2_t{sv[j][2], sv[j][3]}, nm, v23);
+                v01 = __builtin_elementwise_fma(v01, rs, f32x2_t{bv[j][0], bv[j][1]});
+                v23 = __builtin_elementwise_fma(v23, rs, f32x2_t{bv[j][2], bv[j][3]});
+            } else {
+                v01 += f32x2_t{bv[j][0], bv[j][1]};
+                v23 += f32x2_t{bv[j][2], bv[j][3]};
+            }
             if (EPI == OV_EPI_BIAS_GELU_ERF) { v01 = gelu_erf_f2(v01); v23 = gelu_erf_f2(v23); }
             if (EPI == OV_EPI_BIAS_GELU_TANH) { v01 = gelu_tanh_f2(v01); v23 = gelu_tanh_f2(v23); }
             u32x2_t p = {pack_bf16x2(v01[0], v01[1]), pack_bf16x2(v23[0], v23[1])};
@@ -325,17 +358,51 @@ __device__ __forceinline__ void epilogue_2pass(const GemmArgs& g, f32x4_t (&acc)
             bv[j][0] = bv[j][1] = bv[j][2] = bv[j][3] = 0.f;
         }
     }
+    const bool fold = (EPI != OV_EPI_BIAS_RESIDUAL) && g.colsum != nullptr;
+    float sv[4][4];
+    if (fold) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nn = n0 + wn * 64 + j * 16 + fq * 4;
+            if (nn < g.N) {
+                const float4 s4 = *(const float4*)(g.colsum + nn);
+                sv[j][0] = s4.x; sv[j][1] = s4.y; sv[j][2] = s4.z; sv[j][3] = s4.w;
+            } else {
+                sv[j][0] = sv[j][1] = sv[j][2] = sv[j][3] = 0.f;
+            }
+        }
+    }
     const int er = lane >> 3, ec = lane & 7;
     const int n = n0 + wn * 64 + ec * 8;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
+        float rmean[4], rrstd[4];
+        if (fold) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int64_t m = m0 + wm * 128 + (h * 4 + i) * 16 + fr;
+                m = m < g.M ? m : g.M - 1;
+                const float2 st = *(const float2*)(g.rowstats + 2 * m);
+                rmean[i] = st.x; rrstd[i] = st.y;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int ml = i * 16 + fr;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                f32x2_t v01 = f32x2_t{acc[h * 4 + i][j][0], acc[h * 4 + i][j][1]} + f32x2_t{bv[j][0], bv[j][1]};
-                f32x2_t v23 = f32x2_t{acc[h * 4 + i][j][2], acc[h * 4 + i][j][3]} + f32x2_t{bv[j][2], bv[j][3]};
+                f32x2_t v01 = f32x2_t{acc[h * 4 + i][j][0], acc[h * 4 + i][j][1]};
+                f32x2_t v23 = f32x2_t{acc[h * 4 + i][j][2], acc[h * 4 + i][j][3]};
+                if (fold) {      // rstd * (acc - mean * colsum) + cvec, as two explicit FMAs (identical in every kernel variant)
+                    const f32x2_t nm = {-rmean[i], -rmean[i]}, rs = {rrstd[i], rrstd[i]};
+                    v01 = __builtin_elementwise_fma(f32x2_t{sv[j][0], sv[j][1]}, nm, v01);
+                    v23 = __builtin_elementwise_fma(f32x2_t{sv[j][2], sv[j][3]}, nm, v23);
+                    v01 = __builtin_elementwise_fma(v01, rs, f32x2_t{bv[j][0], bv[j][1]});
+                    v23 = __builtin_elementwise_fma(v23, rs, f32x2_t{bv[j][2], bv[j][3]});
+                } else {
+                    v01 += f32x2_t{bv[j][0], bv[j][1]};
+                    v23 += f32x2_t{bv[j][2], bv[j][3]};
+                }
                 if (EPI == OV_EPI_BIAS_GELU_ERF) { v01 = gelu_erf_f2(v01); v23 = gelu_erf_f2(v23); }
                 if (EPI == OV_EPI_BIAS_GELU_TANH) { v01 = gelu_tanh_f2(v01); v23 = gelu_tanh_f2(v23); }
                 u32x2_t pk = {pack_bf16x2(v01[0], v01[1]), pack_bf16x2(v23[0], v23[1])};
@@ -785,6 +852,8 @@ int num_cus() {
     return n;
 }
 
+thread_local const float* g_colsum = nullptr;      // set by ov_gemm_ln around its call into ov_gemm
+thread_local const float* g_rowstats = nullptr;
 unsigned long long* g_stamps = nullptr;
 int g_stamp_slots = 0;
 
@@ -843,7 +912,7 @@ extern "C" int ov_gemm(const ov_bf16* A, int64_t lda, const ov_bf16* W, int64_t 
     const int64_t tiles_n = (N + BN - 1) / BN;
     if (tiles_m * tiles_n > 0x7fffffffLL) return OV_ERR_UNSUPPORTED;
     GemmArgs a{A, W, bias, C, R, lda, ldw, ldc, ldr, M, N, K, (int)tiles_m, (int)tiles_n,
-               out_group, resid_mod, resid_off, g_stamps, g_stamp_slots};
+               out_group, resid_mod, resid_off, g_colsum, g_rowstats, g_stamps, g_stamp_slots};
     hipStream_t st = (hipStream_t)stream;
     switch (epilogue) {
         case OV_EPI_BIAS: return launch<OV_EPI_BIAS>(a, st);
@@ -860,4 +929,18 @@ extern "C" int ov_debug_gemm_stamps(unsigned long long* buf, int slots) {
     g_stamps = buf;
     g_stamp_slots = buf ? slots : 0;
     return OV_OK;
+}
+
+extern "C" int ov_gemm_ln(const ov_bf16* X, int64_t ldx, const ov_bf16* Wg, int64_t ldw, const float* cvec, const float* colsum,
+                          const float* rowstats, ov_bf16* C, int64_t ldc, int64_t M, int N, int K, int epilogue,
+                          ov_stream_t stream) {
+    if (!colsum || !rowstats || !cvec) return OV_ERR_INVALID;
+    if (epilogue == OV_EPI_BIAS_RESIDUAL) return OV_ERR_UNSUPPORTED;
+    if ((((uintptr_t)colsum | (uintptr_t)cvec) & 15) || ((uintptr_t)rowstats & 7)) return OV_ERR_INVALID;
+    g_colsum = colsum;
+    g_rowstats = rowstats;
+    const int rc = ov_gemm(X, ldx, Wg, ldw, cvec, C, ldc, M, N, K, epilogue, nullptr, 0, 0, 0, 0, stream);
+    g_colsum = nullptr;
+    g_rowstats = nullptr;
+    return rc;
 }

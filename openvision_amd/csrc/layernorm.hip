@@ -88,6 +88,51 @@ __global__ __launch_bounds__(256) void layernorm_rows(const void* __restrict__ x
     }
 }
 
+// {mean, rstd} per row only (LN folded into the next GEMM's epilogue): reads the row once, writes 8 bytes.
+template <int NCH>
+__global__ __launch_bounds__(256) void rowstats_rows(const ov_bf16* __restrict__ x, int64_t ldx, float* __restrict__ st,
+                                                     int64_t rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int nchunk = D >> 3;
+    const float invD = 1.0f / (float)D;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        float v[NCH][8];
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int ch = lane + c * 64;
+            if (ch < nchunk) {
+                const u32x4_t w = *(const u32x4_t*)(x + row * ldx + ch * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[c][2 * e] = bf16lo_to_f32(w[e]);
+                    v[c][2 * e + 1] = bf16hi_to_f32(w[e]);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += v[c][e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[c][e] = 0.f;
+            }
+        }
+        const float mean = wave_sum(s) * invD;
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            if (lane + c * 64 < nchunk) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float d = v[c][e] - mean;
+                    q += d * d;
+                }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(q) * invD + eps);
+        if (lane == 0) *(float2*)(st + 2 * row) = make_float2(mean, rstd);
+    }
+}
+
 template <int NCH>
 int launch_ln(const void* x, int xd, int64_t ldx, const float* g, const float* b, void* y, int yd, int64_t ldy,
               int64_t rows, int D, float eps, hipStream_t st) {
@@ -123,4 +168,23 @@ extern "C" int ov_layernorm(const void* x, int x_dtype, int64_t ldx, const float
     if (nch <= 4) return launch_ln<4>(x, x_dtype, ldx, gamma, beta, y, y_dtype, ldy, rows, D, eps, st);
     if (nch <= 8) return launch_ln<8>(x, x_dtype, ldx, gamma, beta, y, y_dtype, ldy, rows, D, eps, st);
     return launch_ln<16>(x, x_dtype, ldx, gamma, beta, y, y_dtype, ldy, rows, D, eps, st);
+}
+
+extern "C" int ov_rowstats(const ov_bf16* x, int64_t ldx, float* rowstats, int64_t rows, int D, float eps, ov_stream_t stream) {
+    if (!x || !rowstats || rows <= 0 || D <= 0) return OV_ERR_INVALID;
+    if (D % 8 || D > 8192 || ldx % 8 || ldx < D) return OV_ERR_UNSUPPORTED;
+    if (((uintptr_t)x & 15) || ((uintptr_t)rowstats & 7)) return OV_ERR_INVALID;
+    int64_t blocks = (rows + 3) / 4;
+    if (blocks > 16384) blocks = 16384;
+    const dim3 grid((unsigned)blocks), blk(256);
+    hipStream_t st = (hipStream_t)stream;
+    const int nch = (D / 8 + 63) / 64;
+    if (nch <= 1) hipLaunchKernelGGL(rowstats_rows<1>, grid, blk, 0, st, x, ldx, rowstats, rows, D, eps);
+    else if (nch <= 2) hipLaunchKernelGGL(rowstats_rows<2>, grid, blk, 0, st, x, ldx, rowstats, rows, D, eps);
+    else if (nch <= 3) hipLaunchKernelGGL(rowstats_rows<3>, grid, blk, 0, st, x, ldx, rowstats, rows, D, eps);
+    else if (nch <= 4) hipLaunchKernelGGL(rowstats_rows<4>, grid, blk, 0, st, x, ldx, rowstats, rows, D, eps);
+    else if (nch <= 8) hipLaunchKernelGGL(rowstats_rows<8>, grid, blk, 0, st, x, ldx, rowstats, rows, D, eps);
+    else hipLaunchKernelGGL(rowstats_rows<16>, grid, blk, 0, st, x, ldx, rowstats, rows, D, eps);
+    OV_LAUNCH_CHECK();
+    return OV_OK;
 }

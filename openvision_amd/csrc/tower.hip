@@ -181,6 +181,8 @@ extern "C" int ov_tower_set_block(ov_tower* t, int layer, const ov_block_weights
                        w->fc_w, w->fc_b, w->proj_w, w->proj_b};
     for (const void* q : p)
         if (!q || ((uintptr_t)q & 15)) return OV_ERR_INVALID;
+    if ((w->qkv_colsum == nullptr) != (w->fc_colsum == nullptr)) return OV_ERR_INVALID;
+    if (((uintptr_t)w->qkv_colsum | (uintptr_t)w->fc_colsum) & 15) return OV_ERR_INVALID;
     t->blocks[layer] = *w;
     t->set[layer] = 1;
     return OV_OK;
@@ -190,19 +192,20 @@ extern "C" size_t ov_tower_workspace_bytes(const ov_tower* t, int B, int L) {
     if (!t || B <= 0 || L <= 0) return 0;
     const size_t M = (size_t)B * L;
     const int D = t->cfg.width;
-    return align_up(M * D * 2, 256) + align_up(M * (size_t)max_i(3 * D, t->cfg.mlp_pad) * 2, 256);
+    return align_up(M * D * 2, 256) + align_up(M * (size_t)max_i(3 * D, t->cfg.mlp_pad) * 2, 256) + align_up(M * 8, 256);
 }
 
 namespace {
 // One ResidualAttentionBlock on rows [0, B*L) of x (in place).  `prof` = record in-situ timings for these launches.
-int run_block(const ov_tower_cfg& c, const ov_block_weights& w, ov_bf16* x, ov_bf16* h, ov_bf16* big, int B, int L,
-              ov_stream_t stream, bool prof) {
+int run_block(const ov_tower_cfg& c, const ov_block_weights& w, ov_bf16* x, ov_bf16* h, ov_bf16* big, float* stats, int B,
+              int L, ov_stream_t stream, bool prof) {
     const int D = c.width, H = c.heads, hd = D / H;
     const int64_t M = (int64_t)B * L;
     const int ldb = 3 * D > c.mlp_pad ? 3 * D : c.mlp_pad;      // row pitch of `big` (shared by qkv and the MLP hidden)
     const float scale = 1.0f / sqrtf((float)hd);
     const int gelu = c.gelu_tanh ? OV_EPI_BIAS_GELU_TANH : OV_EPI_BIAS_GELU_ERF;
     const int fc_cls = c.gelu_tanh ? OV_PROF_GEMM_FC_TANH : OV_PROF_GEMM_FC;
+    const bool fold = w.qkv_colsum != nullptr && w.fc_colsum != nullptr;   // LN folded into the QKV / c_fc epilogues
     int rc;
 #define OV_STEP(cls, call)                                           \
     do {                                                             \
@@ -210,12 +213,22 @@ int run_block(const ov_tower_cfg& c, const ov_block_weights& w, ov_bf16* x, ov_b
         else rc = (call);                                            \
         if (rc) return rc;                                           \
     } while (0)
-    OV_STEP(OV_PROF_LN, ov_layernorm(x, OV_BF16, D, w.ln1_w, w.ln1_b, h, OV_BF16, D, M, D, c.ln_eps, stream));
-    OV_STEP(OV_PROF_GEMM_QKV, ov_gemm(h, D, w.qkv_w, D, w.qkv_b, big, ldb, M, 3 * D, D, OV_EPI_BIAS, nullptr, 0, 0, 0, 0, stream));
+    if (fold) {
+        OV_STEP(OV_PROF_LN, ov_rowstats(x, D, stats, M, D, c.ln_eps, stream));
+        OV_STEP(OV_PROF_GEMM_QKV, ov_gemm_ln(x, D, w.qkv_w, D, w.qkv_b, w.qkv_colsum, stats, big, ldb, M, 3 * D, D, OV_EPI_BIAS, stream));
+    } else {
+        OV_STEP(OV_PROF_LN, ov_layernorm(x, OV_BF16, D, w.ln1_w, w.ln1_b, h, OV_BF16, D, M, D, c.ln_eps, stream));
+        OV_STEP(OV_PROF_GEMM_QKV, ov_gemm(h, D, w.qkv_w, D, w.qkv_b, big, ldb, M, 3 * D, D, OV_EPI_BIAS, nullptr, 0, 0, 0, 0, stream));
+    }
     OV_STEP(OV_PROF_ATTN, ov_attention(big, ldb, h, D, B, L, H, hd, scale, stream));
     OV_STEP(OV_PROF_GEMM_OUT, ov_gemm(h, D, w.out_w, D, w.out_b, x, D, M, D, D, OV_EPI_BIAS_RESIDUAL, x, D, 0, 0, 0, stream));
-    OV_STEP(OV_PROF_LN, ov_layernorm(x, OV_BF16, D, w.ln2_w, w.ln2_b, h, OV_BF16, D, M, D, c.ln_eps, stream));
-    OV_STEP(fc_cls, ov_gemm(h, D, w.fc_w, D, w.fc_b, big, ldb, M, c.mlp_pad, D, gelu, nullptr, 0, 0, 0, 0, stream));
+    if (fold) {
+        OV_STEP(OV_PROF_LN, ov_rowstats(x, D, stats, M, D, c.ln_eps, stream));
+        OV_STEP(fc_cls, ov_gemm_ln(x, D, w.fc_w, D, w.fc_b, w.fc_colsum, stats, big, ldb, M, c.mlp_pad, D, gelu, stream));
+    } else {
+        OV_STEP(OV_PROF_LN, ov_layernorm(x, OV_BF16, D, w.ln2_w, w.ln2_b, h, OV_BF16, D, M, D, c.ln_eps, stream));
+        OV_STEP(fc_cls, ov_gemm(h, D, w.fc_w, D, w.fc_b, big, ldb, M, c.mlp_pad, D, gelu, nullptr, 0, 0, 0, 0, stream));
+    }
     OV_STEP(OV_PROF_GEMM_PROJ, ov_gemm(big, ldb, w.proj_w, c.mlp_pad, w.proj_b, x, D, M, D, c.mlp_pad, OV_EPI_BIAS_RESIDUAL, x,
                                        D, 0, 0, 0, stream));
 #undef OV_STEP
@@ -277,6 +290,7 @@ extern "C" int ov_tower_forward(const ov_tower* t, ov_bf16* x, int B, int L, voi
     const int ldb = 3 * D > c.mlp_pad ? 3 * D : c.mlp_pad;
     ov_bf16* h = (ov_bf16*)workspace;
     ov_bf16* big = (ov_bf16*)((char*)workspace + align_up((size_t)M * D * 2, 256));
+    float* stats = (float*)((char*)big + align_up((size_t)M * ldb * 2, 256));   // {mean, rstd} per row (LN fold)
     for (int i = 0; i < c.layers; ++i)
         if (!t->set[i]) return OV_ERR_INVALID;
 
@@ -292,10 +306,11 @@ extern "C" int ov_tower_forward(const ov_tower* t, ov_bf16* x, int B, int L, voi
     }
     const int64_t off = (int64_t)Bm * L;
     for (int i = 0; i < c.layers; ++i) {
-        int rc = run_block(c, t->blocks[i], x, h, big, Bm, L, stream, true);
+        int rc = run_block(c, t->blocks[i], x, h, big, stats, Bm, L, stream, true);
         if (rc) return rc;
         if (nt > 0) {
-            rc = run_block(c, t->blocks[i], x + off * D, h + off * D, big + off * ldb, nt, L, (ov_stream_t)tc->stream, false);
+            rc = run_block(c, t->blocks[i], x + off * D, h + off * D, big + off * ldb, stats + 2 * off, nt, L,
+                           (ov_stream_t)tc->stream, false);
             if (rc) return rc;
         }
     }

@@ -266,18 +266,38 @@ class ResidualAttentionBlock(nn.Module):
         self.ls_2 = nn.Identity()
         self.gelu_tanh = gelu_is_tanh(act_kwargs)
         self.mlp_dim, self.mlp_pad = mlp, _round_up(mlp, 64)
+        self._fold_pk = _Packed()
 
-    def packed_block(self) -> "_lib.BlockWeights":
+    def packed_block(self, fold_ln: bool = True):
+        """Device weights of this block in the kernels' layout.  With ``fold_ln`` (default; ``OVHIP_NO_LN_FOLD=1`` disables)
+        ln_1 / ln_2 are folded into the QKV / c_fc GEMMs: W' = bf16(gamma * W), colsum = sum_k W', cvec = beta @ W^T + b
+        (see ov_gemm_ln in include/ovhip.h); the LayerNorm output is never materialised."""
         d = self.attn.embed_dim
+        dev = self.attn.in_proj_weight.device
         g1, b1 = self.ln_1.packed()
         g2, b2 = self.ln_2.packed()
-        wq, bq = self.attn.packed_in()
         wo, bo = self.attn.out_proj.packed(d, _round_up(d, 64))
-        wf, bf = self.mlp.c_fc.packed(self.mlp_pad, _round_up(d, 64))
         wp, bp = self.mlp.c_proj.packed(d, self.mlp_pad)
-        keep = (g1, b1, wq, bq, wo, bo, g2, b2, wf, bf, wp, bp)
-        bw = _lib.BlockWeights(*[C.c_void_p(t.data_ptr()) for t in keep])
-        return bw, keep
+        if not fold_ln:
+            wq, bq = self.attn.packed_in()
+            wf, bf = self.mlp.c_fc.packed(self.mlp_pad, _round_up(d, 64))
+            keep = (g1, b1, wq, bq, wo, bo, g2, b2, wf, bf, wp, bp)
+            return _lib.BlockWeights(*[C.c_void_p(t.data_ptr()) for t in keep], None, None), keep
+
+        def fold(w, b, gamma, beta, n_pad):
+            w32 = w.detach().float()
+            wg = _pack_matrix(w32 * gamma[None, :], n_pad, _round_up(d, 64))          # bf16(gamma * W), zero padded
+            colsum = wg.float().sum(dim=1).contiguous()                               # sums of the ROUNDED weights
+            cvec = _pack_vec((w32.to(torch.bfloat16).float() @ beta) + (b.detach().float() if b is not None else 0.0),
+                             n_pad, dev)
+            return wg, cvec, colsum
+
+        key = (self.ln_1.weight, self.ln_1.bias, self.ln_2.weight, self.ln_2.bias, self.attn.in_proj_weight,
+               self.attn.in_proj_bias, self.mlp.c_fc.weight, self.mlp.c_fc.bias)
+        wq, cq, sq, wf, cf, sf = self._fold_pk.get(key, lambda: fold(self.attn.in_proj_weight, self.attn.in_proj_bias, g1, b1, 3 * d)
+                                                    + fold(self.mlp.c_fc.weight, self.mlp.c_fc.bias, g2, b2, self.mlp_pad))
+        keep = (g1, b1, wq, cq, wo, bo, g2, b2, wf, cf, wp, bp, sq, sf)
+        return _lib.BlockWeights(*[C.c_void_p(t.data_ptr()) for t in keep]), keep
 
     def forward(self, q_x: torch.Tensor, k_x=None, v_x=None, attn_mask=None) -> torch.Tensor:
         if k_x is not None or v_x is not None or attn_mask is not None:
@@ -300,7 +320,7 @@ class _TowerHandle:
             raise _lib.OvhipError("ov_tower_create failed (invalid tower configuration)")
         self.keep = []
         for i, blk in enumerate(blocks):
-            bw, keep = blk.packed_block()
+            bw, keep = blk.packed_block(fold_ln=os.environ.get("OVHIP_NO_LN_FOLD", "0") != "1")
             self.keep.append(keep)
             check(lib.ov_tower_set_block(self.handle, i, C.byref(bw)), "ov_tower_set_block")
         self.width, self.layers = d, len(blocks)

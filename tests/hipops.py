@@ -49,3 +49,20 @@ def clip_loss(img, txt, all_img, all_txt, scale, label_offset):
     check(lib.ov_clip_loss(ptr(img), ptr(txt), ptr(all_img), ptr(all_txt), b, n, e, float(scale), label_offset, ptr(out),
                            ptr(terms), ptr(ws), nb, stream_ptr()))
     return out[0], terms
+
+
+def rowstats(x, eps=1e-6):
+    lib = _lib.load()
+    st = torch.empty(x.shape[0], 2, dtype=torch.float32, device=x.device)
+    check(lib.ov_rowstats(ptr(x), x.stride(0), ptr(st), x.shape[0], x.shape[1], eps, stream_ptr()))
+    return st
+
+
+def gemm_ln(x, wg, cvec, colsum, stats, epi=0):
+    lib = _lib.load()
+    m, k = x.shape
+    n = wg.shape[0]
+    out = torch.empty(m, n, dtype=torch.bfloat16, device=x.device)
+    check(lib.ov_gemm_ln(ptr(x), x.stride(0), ptr(wg), wg.stride(0), ptr(cvec), ptr(colsum), ptr(stats), ptr(out), out.stride(0),
+                         m, n, k, epi, stream_ptr()))
+    return out

@@ -57,6 +57,27 @@ def test_gemm_gelu(epi, tanh):
     np.testing.assert_allclose(c.numpy(), ref.numpy(), rtol=1e-2, atol=1e-2)
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(771, 3072, 1024, 0), (300, 768, 192, 1), (65535, 1024, 1024, 0), (200, 2304, 768, 2)])
+def test_gemm_ln_fold_matches_layernorm_then_linear(M, N, K, epi):
+    """ov_rowstats + ov_gemm_ln == Linear(LayerNorm(x)) (transformer.py:263-264) without materialising LN(x)."""
+    x = (rnd(M, K, seed=30) * 1.7 + 0.4).to(torch.bfloat16)
+    w, bias = rnd(N, K, seed=31) / K ** 0.5, rnd(N, seed=32) * 0.1
+    gamma, beta = rnd(K, seed=33) * 0.1 + 1, rnd(K, seed=34) * 0.1
+    wg = (w * gamma[None, :]).to(torch.bfloat16)
+    colsum = wg.float().sum(1)
+    cvec = w.to(torch.bfloat16).float() @ beta + bias
+    xd = x.to(DEV)
+    st = H.rowstats(xd)
+    ref_mean = x.float().mean(1)
+    np.testing.assert_allclose(st[:, 0].cpu().numpy(), ref_mean.numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(st[:, 1].cpu().numpy(), (x.float().var(1, unbiased=False) + 1e-6).rsqrt().numpy(), rtol=1e-5)
+    c = H.gemm_ln(xd, wg.to(DEV), cvec.to(DEV), colsum.to(DEV), st, epi=epi).float().cpu()
+    ref = torch.nn.functional.linear(R.layer_norm(x.float(), gamma, beta), w, bias)
+    if epi:
+        ref = R.gelu(ref, epi == 2)
+    np.testing.assert_allclose(c.numpy(), ref.numpy(), rtol=1.5e-2, atol=2e-2)
+
+
 def test_gemm_residual_inplace():
     M, N, K = 514, 1024, 1024
     a, w, bias = rnd(M, K, seed=13).to(torch.bfloat16), (rnd(N, K, seed=14) / K ** 0.5).to(torch.bfloat16), rnd(N, seed=15)
