@@ -278,7 +278,10 @@ __device__ __forceinline__ u32x2_t tr_read_off(unsigned addr) {
     return v;
 }
 
-__global__ __launch_bounds__(640, 3) void attn_fwd_hd64_persist(const AttnPArgs a) {
+// DEEP = workgroups of <= 8 waves (2 per SIMD, 256 VGPRs each): both K tiles of the next step are fetched behind the S MFMAs
+// and all V fragments of a step are in flight from its start.
+template <bool DEEP>
+__global__ __launch_bounds__(DEEP ? 512 : 640, DEEP ? 2 : 3) void attn_fwd_hd64_persist(const AttnPArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -373,15 +376,22 @@ __global__ __launch_bounds__(640, 3) void attn_fwd_hd64_persist(const AttnPArgs 
         };
         const int npair = nk_tiles >> 1;
         load_k(kfa, 0);
+        if (DEEP && npair > 0) load_k(kfb, 1);
         for (int it = 0; it < npair; ++it) {
             const int kt = 2 * it;
             const unsigned va0 = ks_u + kt * 2048 + v_lane0, va1 = ks_u + kt * 2048 + v_lane1;
-            load_k(kfb, kt + 1);                                       // second tile's K: covered by the first tile's MFMAs
+            if (!DEEP) load_k(kfb, kt + 1);                            // second tile's K: covered by the first tile's MFMAs
             u32x2_t vt[8], vu[8];
             vt[0] = tr_read_off<0>(va0);    vt[1] = tr_read_off<512>(va0);
             vt[2] = tr_read_off<0>(va1);    vt[3] = tr_read_off<512>(va1);
             vt[4] = tr_read_off<1024>(va0); vt[5] = tr_read_off<1536>(va0);
             vt[6] = tr_read_off<1024>(va1); vt[7] = tr_read_off<1536>(va1);
+            if (DEEP) {
+                vu[0] = tr_read_off<2048>(va0); vu[1] = tr_read_off<2560>(va0);
+                vu[2] = tr_read_off<2048>(va1); vu[3] = tr_read_off<2560>(va1);
+                vu[4] = tr_read_off<3072>(va0); vu[5] = tr_read_off<3584>(va0);
+                vu[6] = tr_read_off<3072>(va1); vu[7] = tr_read_off<3584>(va1);
+            }
             f32x16_t sa, sb;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { sa[i] = 0.f; sb[i] = 0.f; }
@@ -390,6 +400,7 @@ __global__ __launch_bounds__(640, 3) void attn_fwd_hd64_persist(const AttnPArgs 
 #pragma unroll
             for (int st = 0; st < 4; ++st) sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfb[st], qf[st], sb, 0, 0, 0);
             if (kt + 2 < nk_tiles) load_k(kfa, kt + 2);                // next step's first tile, fetched under the softmax
+            if (DEEP && kt + 3 < nk_tiles) load_k(kfb, kt + 3);
             mask_tail(sb, kt + 1);
             float mx = fmaxf(tile_max(sa), tile_max(sb));
             {
@@ -412,11 +423,12 @@ __global__ __launch_bounds__(640, 3) void attn_fwd_hd64_persist(const AttnPArgs 
             const bf16x8_t pa0 = pack_p(sa, 0), pa1 = pack_p(sa, 1), pb0 = pack_p(sb, 0), pb1 = pack_p(sb, 1);
             tr_wait(vt);
             __builtin_amdgcn_sched_barrier(0);
-            // second tile's V fragments: their LDS latency hides under the first tile's four P.V MFMAs
-            vu[0] = tr_read_off<2048>(va0); vu[1] = tr_read_off<2560>(va0);
-            vu[2] = tr_read_off<2048>(va1); vu[3] = tr_read_off<2560>(va1);
-            vu[4] = tr_read_off<3072>(va0); vu[5] = tr_read_off<3584>(va0);
-            vu[6] = tr_read_off<3072>(va1); vu[7] = tr_read_off<3584>(va1);
+            if (!DEEP) {   // second tile's V fragments: their LDS latency hides under the first tile's four P.V MFMAs
+                vu[0] = tr_read_off<2048>(va0); vu[1] = tr_read_off<2560>(va0);
+                vu[2] = tr_read_off<2048>(va1); vu[3] = tr_read_off<2560>(va1);
+                vu[4] = tr_read_off<3072>(va0); vu[5] = tr_read_off<3584>(va0);
+                vu[6] = tr_read_off<3072>(va1); vu[7] = tr_read_off<3584>(va1);
+            }
             o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join(vt[0], vt[1]), pa0, o0, 0, 0, 0);
             o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join(vt[2], vt[3]), pa0, o1, 0, 0, 0);
             o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join(vt[4], vt[5]), pa1, o0, 0, 0, 0);
@@ -511,8 +523,10 @@ extern "C" int ov_attention(const ov_bf16* qkv, int64_t ld_qkv, ov_bf16* out, in
         p.L = L; p.H = H; p.nqt = a.nqt; p.KC = lp; p.nheads = B * H; p.scale_log2 = a.scale_log2;
         static bool attr2 = false;
         if (!attr2) {
-            hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_hd64_persist, hipFuncAttributeMaxDynamicSharedMemorySize,
+            hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_hd64_persist<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                160 * 1024);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute((const void*)attn_fwd_hd64_persist<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return OV_ERR_HIP - (int)e;
             attr2 = true;
         }
@@ -525,12 +539,15 @@ extern "C" int ov_attention(const ov_bf16* qkv, int64_t ld_qkv, ov_bf16* out, in
         }
         const size_t smem = (size_t)2 * lp * 256;
         int per_cu = (int)((160 * 1024) / smem);                  // workgroups per CU by LDS ...
-        const int by_waves = 12 / a.nqt;                          // ... and by waves (<= 3 per SIMD at <= 168 VGPRs)
+        const int by_waves = (a.nqt <= 8 ? 8 : 12) / a.nqt;       // ... and by waves (2 per SIMD for the DEEP variant, else 3)
         if (per_cu > by_waves) per_cu = by_waves;
         if (per_cu < 1) per_cu = 1;
         const int cap = ncu * per_cu;
         const int grid = p.nheads < cap ? p.nheads : cap;
-        hipLaunchKernelGGL(attn_fwd_hd64_persist, dim3((unsigned)grid), dim3(a.nqt * 64), smem, (hipStream_t)stream, p);
+        if (a.nqt <= 8)
+            hipLaunchKernelGGL(attn_fwd_hd64_persist<true>, dim3((unsigned)grid), dim3(a.nqt * 64), smem, (hipStream_t)stream, p);
+        else
+            hipLaunchKernelGGL(attn_fwd_hd64_persist<false>, dim3((unsigned)grid), dim3(a.nqt * 64), smem, (hipStream_t)stream, p);
         OV_LAUNCH_CHECK();
         return OV_OK;
     }

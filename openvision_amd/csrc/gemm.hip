@@ -447,7 +447,7 @@ __device__ __forceinline__ void epilogue_2pass(const GemmArgs& g, f32x4_t (&acc)
 
 template <int EPI>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist(const GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES + 2048];   // + 256 B per wave: dump for the residual prefetch
+    __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -505,11 +505,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist(const GemmArgs 
     const int a_lane = (wm * 128 + fr) * 64 + lsw;
     const int w_lane = PIECE_BYTES + (wn * 64 + fr) * 64 + lsw;
     const int nt = g.K / BK;
-    // Residual epilogue: every CU would read its 128-KiB residual tile in one burst right behind its last MFMA, all CUs at
-    // once (HBM-latency bound, ~12 us per tile).  Three K-tiles ahead each thread touches its 2 of the tile's 1024 lines
-    // with a 4-byte LDS-DMA into a dump area, so the epilogue's 16-byte reads hit L2 / Infinity Cache instead.
-    const int pf_t = (EPI == OV_EPI_BIAS_RESIDUAL && g.resid_mod == 0 && nt >= 4) ? nt - 3 : -1;
-
     set_tile(tcur, asrc, wsrc, m0, n0);
 #pragma unroll
     for (int j = 0; j < 4; ++j) stage_piece(asrc, wsrc, 0, j, 0);
@@ -557,21 +552,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist(const GemmArgs 
                 }
                 if (p & 1) {
                     // K-tile 0 of every tile was fully waited for (prologue / previous epilogue): no wait at t == 0, p == 1
-                    if (more) {
-                        if (p == 1 && t == pf_t + 1 && pf_t >= 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // + 2 prefetches
-                        else if (t > 0 || p == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                    } else if (p == 1 && t > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (EPI == OV_EPI_BIAS_RESIDUAL && p == 3 && t == pf_t) {
-                        int64_t pr = m0 + (tid >> 1);
-                        pr = pr < g.M ? pr : g.M - 1;
-                        const ov_bf16* rp = g.R + pr * g.ldr;
-#pragma unroll
-                        for (int i = 0; i < 2; ++i) {
-                            int pc = n0 + ((tid & 1) * 2 + i) * 64;
-                            pc = pc < g.N ? pc : g.N - 2;
-                            __builtin_amdgcn_global_load_lds((gptr_t)(rp + pc), (lptr_t)(smem + SMEM_BYTES + wave * 256), 4, 0, 0);
-                        }
-                    }
+                    if (more) { if (t > 0 || p == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+                    else if (p == 1 && t > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
@@ -606,239 +588,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist(const GemmArgs 
     }
 }
 
-// Two-phase variant of the persistent ping-pong kernel: a K-tile is two phases of 32 MFMAs (one per k-half) instead of four
-// of 16 -- half as many barriers per FLOP; the LOAD segment carries 12 ds_read_b128 + 4 LDS-DMA pieces.
-template <int EPI>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist2(const GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES + 2048];   // + 256 B per wave: dump for the residual prefetch
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-    // ---- static persistent schedule: XCD x owns a contiguous run of tiles (n fastest), its workgroups stride it ----
-    const int nwg = g.tiles_m * g.tiles_n;
-    const int G = gridDim.x, bid = blockIdx.x;
-    const int xcd = bid & 7, li = bid >> 3;
-    const int q8 = nwg >> 3, r8 = nwg & 7;
-    const int xstart = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
-    const int xcnt = q8 + (xcd < r8 ? 1 : 0);
-    const int nper = (G - xcd + 7) >> 3;
-    int tcur = li;
-    if (tcur >= xcnt) return;
-
-    const int srow = tid >> 2;
-    const int schunk = (tid & 3) ^ swz4(srow);
-    const ov_bf16* asrc[2];
-    const ov_bf16* wsrc[2];
-    const ov_bf16* nasrc[2];
-    const ov_bf16* nwsrc[2];
-    int64_t m0, nm0 = 0;
-    int n0, nn0 = 0;
-    auto set_tile = [&](int trel, const ov_bf16* (&as)[2], const ov_bf16* (&ws)[2], int64_t& mm, int& nn) {
-        const int wg = xstart + trel;
-        const int tm = wg / g.tiles_n, tn = wg - tm * g.tiles_n;
-        mm = (int64_t)tm * BM;
-        nn = tn * BN;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int64_t ar = mm + i * 128 + srow;
-            ar = ar < g.M ? ar : g.M - 1;
-            int wr = nn + i * 128 + srow;
-            wr = wr < g.N ? wr : g.N - 1;
-            as[i] = g.A + ar * g.lda + schunk * 8;
-            ws[i] = g.W + (int64_t)wr * g.ldw + schunk * 8;
-        }
-    };
-    char* const sbase = smem + wave * 1024;
-    auto stage_piece = [&](const ov_bf16* const (&as)[2], const ov_bf16* const (&ws)[2], int buf, int j, int k0) {
-        char* dst = sbase + buf * STAGE_BYTES + j * PIECE_BYTES;
-        const int kk = k0 + (j >> 1) * 32;
-        if (j & 1) {
-            __builtin_amdgcn_global_load_lds((gptr_t)(ws[0] + kk), (lptr_t)dst, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(ws[1] + kk), (lptr_t)(dst + 8192), 16, 0, 0);
-        } else {
-            __builtin_amdgcn_global_load_lds((gptr_t)(as[0] + kk), (lptr_t)dst, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(as[1] + kk), (lptr_t)(dst + 8192), 16, 0, 0);
-        }
-    };
-
-    const int wm = wave >> 2, wn = wave & 3;
-    const int fr = lane & 15, fq = lane >> 4;
-    const int lsw = (fq ^ swz4(fr)) << 4;
-    const int a_lane = (wm * 128 + fr) * 64 + lsw;
-    const int w_lane = PIECE_BYTES + (wn * 64 + fr) * 64 + lsw;
-    const int nt = g.K / BK;
-    // Residual epilogue: every CU would read its 128-KiB residual tile in one burst right behind its last MFMA, all CUs at
-    // once (HBM-latency bound, ~12 us per tile).  Three K-tiles ahead each thread touches its 2 of the tile's 1024 lines
-    // with a 4-byte LDS-DMA into a dump area, so the epilogue's 16-byte reads hit L2 / Infinity Cache instead.
-    const int pf_t = (EPI == OV_EPI_BIAS_RESIDUAL && g.resid_mod == 0 && nt >= 4) ? nt - 3 : -1;
-
-    set_tile(tcur, asrc, wsrc, m0, n0);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) stage_piece(asrc, wsrc, 0, j, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (wm == 1) __builtin_amdgcn_s_barrier();                     // stagger the lower wave group by one interval
-
-    int par = 0;
-    for (;;) {
-        const int tnext = tcur + nper;
-        const bool has_next = tnext < xcnt;
-        if (has_next) set_tile(tnext, nasrc, nwsrc, nm0, nn0);
-
-        f32x4_t acc[8][4];
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-        bf16x8_t af[8], wf[4];
-        for (int t = 0; t < nt; ++t) {
-            const char* s = smem + ((par + t) & 1) * STAGE_BYTES;
-            const bool last = (t == nt - 1);
-            const bool more = !last || has_next;
-            const int nbuf = (par + t + 1) & 1;
-#pragma unroll
-            for (int kh = 0; kh < 2; ++kh) {
-                // ---------------- LOAD segment: one k-half = 12 ds_read_b128 + 4 LDS-DMA pieces ----------------
-                const char* sp = s + kh * (2 * PIECE_BYTES);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) wf[j] = *(const bf16x8_t*)(sp + w_lane + j * 1024);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) af[i] = *(const bf16x8_t*)(sp + a_lane + i * 1024);
-                if (more) {
-                    if (!last) { stage_piece(asrc, wsrc, nbuf, 2 * kh, (t + 1) * BK); stage_piece(asrc, wsrc, nbuf, 2 * kh + 1, (t + 1) * BK); }
-                    else { stage_piece(nasrc, nwsrc, nbuf, 2 * kh, 0); stage_piece(nasrc, nwsrc, nbuf, 2 * kh + 1, 0); }
-                    // K-tile 0 of every tile was fully waited for (prologue / previous epilogue): its k1 half needs no wait
-                    if (!(t == 0 && kh == 0)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                } else if (kh == 0 && t > 0) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-                // ---------------- COMPUTE segment: 32 MFMAs ----------------
-                __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
-                __builtin_amdgcn_s_setprio(0);
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        if (wm == 0) __builtin_amdgcn_s_barrier();                 // re-align: every wave is past its last COMPUTE segment
-        char* ep = smem + ((par + nt - 1) & 1) * STAGE_BYTES + wave * 8192;
-        epilogue_2pass<EPI>(g, acc, ep, m0, n0, wave, lane, has_next, false);
-        if (!has_next) break;
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();                               // next K-tile 0 visible to all; epilogue image is dead
-        if (wm == 1) __builtin_amdgcn_s_barrier();                  // re-stagger
-        par = (par + nt) & 1;
-        asrc[0] = nasrc[0]; asrc[1] = nasrc[1]; wsrc[0] = nwsrc[0]; wsrc[1] = nwsrc[1];
-        m0 = nm0; n0 = nn0;
-        tcur = tnext;
-    }
-}
-
-// =====================================================================================================
-// Dual-workgroup kernel: 128 x 256 output tile per 4-wave workgroup, TWO workgroups resident per CU (72 KiB LDS and
-// <= 256 VGPRs each), K-step 32 in a 3-deep LDS-DMA ring.  Each SIMD hosts one wave of each workgroup, and the two
-// workgroups drift apart in time: while one waits at its K-step barrier / LDS reads, runs its epilogue (bias, GELU,
-// transpose, residual read, stores) or fetches its first tiles, the other keeps the matrix pipe busy -- the epilogue is
-// overlapped without double-buffering 128 accumulator registers, and different CUs no longer hit HBM in lockstep.
-//   ring slot (24 KiB) = [A piece: 128 rows x 64 B][W piece: 256 rows x 64 B], chunk swizzle f((row>>2)&3) as above
-//   step t: vmcnt(6) (slot t landed, t+1 may fly) -> barrier -> DMA slot t+2 -> 12 ds_read_b128 -> 32 MFMAs
-constexpr int DBM = 128;
-constexpr int DSLOT = 24 * 1024;
-constexpr int DSMEM = 3 * DSLOT;
-
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_dual(const GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) char smem[DSMEM];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // = column group wn; all waves span the 128 rows
-
-    const int nwg = g.tiles_m * g.tiles_n;
-    const int bid = blockIdx.x;
-    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-    const int tm = wgid / g.tiles_n, tn = wgid - tm * g.tiles_n;
-    const int64_t m0 = (int64_t)tm * DBM;
-    const int n0 = tn * BN;
-
-    const int srow = tid >> 2;                                          // 0..63
-    const int schunk = (tid & 3) ^ swz4(srow);
-    const ov_bf16* asrc[2];
-    const ov_bf16* wsrc[4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        int64_t ar = m0 + i * 64 + srow;
-        ar = ar < g.M ? ar : g.M - 1;
-        asrc[i] = g.A + ar * g.lda + schunk * 8;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int wr = n0 + i * 64 + srow;
-        wr = wr < g.N ? wr : g.N - 1;
-        wsrc[i] = g.W + (int64_t)wr * g.ldw + schunk * 8;
-    }
-    char* const sbase = smem + wave * 1024;
-    auto stage = [&](int slot, int k0) {
-        char* dst = sbase + slot * DSLOT;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + k0), (lptr_t)(dst + i * 4096), 16, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + k0), (lptr_t)(dst + 8192 + i * 4096), 16, 0, 0);
-    };
-
-    const int fr = lane & 15, fq = lane >> 4;
-    const int lsw = (fq ^ swz4(fr)) << 4;
-    const int a_lane = fr * 64 + lsw;                                   // + i*1024
-    const int w_lane = 8192 + (wave * 64 + fr) * 64 + lsw;              // + j*1024
-
-    f32x4_t acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-    const int nt = g.K / 32;
-    stage(0, 0);
-    if (nt > 1) stage(1, 32);
-    int slot = 0, slot2 = 2;
-    for (int t = 0; t < nt; ++t) {
-        if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        if (t + 2 < nt) stage(slot2, (t + 2) * 32);
-        const char* s = smem + slot * DSLOT;
-        bf16x8_t af[8], wf[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) wf[j] = *(const bf16x8_t*)(s + w_lane + j * 1024);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) af[i] = *(const bf16x8_t*)(s + a_lane + i * 1024);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        slot = slot == 2 ? 0 : slot + 1;
-        slot2 = slot2 == 2 ? 0 : slot2 + 1;
-    }
-    __builtin_amdgcn_s_barrier();                                        // every wave is done reading the ring
-    epilogue_2pass<EPI>(g, acc, smem + wave * 8192, m0, n0, wave, lane, false, false);
-}
-
 int num_cus() {
     static int n = 0;
     if (n == 0) {
@@ -857,11 +606,11 @@ thread_local const float* g_rowstats = nullptr;
 unsigned long long* g_stamps = nullptr;
 int g_stamp_slots = 0;
 
-int gemm_variant() {       // 0 = persistent ping-pong (default), 1 = v1 two-stage, 2 = non-persistent ping-pong, 3 = dual-WG 128x256
+int gemm_variant() {       // 0 = persistent ping-pong (default), 1 = v1 two-stage, 2 = non-persistent ping-pong
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("OVHIP_GEMM_VARIANT");
-        v = (e && e[0] >= '0' && e[0] <= '4') ? e[0] - '0' : 0;
+        v = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 0;
     }
     return v;
 }
@@ -869,22 +618,13 @@ int gemm_variant() {       // 0 = persistent ping-pong (default), 1 = v1 two-sta
 template <int EPI>
 int launch(GemmArgs a, hipStream_t st) {
     int var = gemm_variant();
-    if (var == 3) {                         // 128-row tiles, two workgroups per CU
-        a.tiles_m = (int)((a.M + DBM - 1) / DBM);
-        hipLaunchKernelGGL(gemm_bf16_dual<EPI>, dim3(a.tiles_m * a.tiles_n), dim3(256), 0, st, a);
-        OV_LAUNCH_CHECK();
-        return OV_OK;
-    }
     const int nwg = a.tiles_m * a.tiles_n;
     // fewer tiles than CUs (pooled heads, the tower's tail images): persistence buys nothing, use the plain launch
-    if ((var == 0 || var == 4) && nwg < num_cus()) var = 2;
+    if (var == 0 && nwg < num_cus()) var = 2;
     if (var == 1) {
         hipLaunchKernelGGL(gemm_bf16_256x256<EPI>, dim3(nwg), dim3(NTHREADS), 0, st, a);
     } else if (var == 2) {
         hipLaunchKernelGGL(gemm_bf16_pp<EPI>, dim3(nwg), dim3(NTHREADS), 0, st, a);
-    } else if (var == 4) {
-        const int ncu = num_cus();
-        hipLaunchKernelGGL(gemm_bf16_persist2<EPI>, dim3(nwg < ncu ? nwg : ncu), dim3(NTHREADS), 0, st, a);
     } else {
         const int ncu = num_cus();
         hipLaunchKernelGGL(gemm_bf16_persist<EPI>, dim3(nwg < ncu ? nwg : ncu), dim3(NTHREADS), 0, st, a);

@@ -3,7 +3,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import hipops as H
-B, L, Hh = 256, 257, 16
+B, L, Hh = 256, int(os.environ.get("L", "257")), 16
 qkv = torch.randn(B * L, 3 * Hh * 64, device="cuda").to(torch.bfloat16)
 for _ in range(3):
     H.attention(qkv, B, L, Hh)
