@@ -180,7 +180,8 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "images/sec (node) ViT-L/14@224 fwd+InfoNCE",
+            "metric": "images/sec (node) ViT-L/14@224 fwd+InfoNCE" if a.model == "vit-large-patch14-224"
+                      else f"images/sec (node) {a.model} fwd+InfoNCE",
             "value": round(world * b * a.steps / dt, 2),
             "unit": "images/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -193,7 +194,8 @@ def main():
                        "gflop_per_pair": round(flops["pair"] / 1e9, 2),
                        "model_tflops_per_gpu": round(flops["pair"] * b * a.steps / dt / 1e12, 1)},
             "loss": round(loss_val, 5),
-            "roofline": {"bound": "mfma", "kernel": "gemm_bf16<bias+erf-GELU> = vision mlp.c_fc, M=b*257 N=4096 K=1024 (rocprof: gemm_bf16_*<1>)",
+            "roofline": {"bound": "mfma", "kernel": f"gemm_bf16_persist<1> (bias + erf-GELU) = vision mlp.c_fc, N={int(Dv * cfg['vision_cfg']['mlp_ratio'])} K={Dv}, "
+                                   f"M={int(rows.value / launches)} rows per launch",
                          "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                          "avg_launch_ms": round(avg_ms, 4), "launches": cnt.value,

@@ -138,6 +138,32 @@ def test_small8_384_long_sequence():
     assert one_minus_cos(fi, g["image_features"]) < COS_TOL
 
 
+@pytest.mark.timeout(900)
+def test_full_size_batch256_properties():
+    """BASELINE config #2/#3 size (ViT-L/14@224, per-GPU batch 256): size-independent properties instead of a CPU oracle
+    run (the fp32 CPU path needs minutes per batch): batch-composition invariance across the persistent/tail-split
+    scheduling, loss symmetry, and 'mean of the 8 ranks' local strip losses == the global loss' (SURVEY.md §3.3)."""
+    cfg = preset("vit-large-patch14-224")
+    m = create_model(cfg, device=DEV, state_dict=synth.make_state_dict(cfg))
+    img = synth.make_images(256, 224, seed=9).to(DEV).to(torch.bfloat16)
+    tok = synth.make_captions(256, seed=9).to(DEV)
+    ni, nt, s = m(img, tok)
+    assert torch.isfinite(ni).all() and torch.isfinite(nt).all()
+    np.testing.assert_allclose(ni.norm(dim=-1).cpu().numpy(), 1.0, atol=1e-5)
+    parts = torch.cat([m.encode_image(img[:100], normalize=True), m.encode_image(img[100:], normalize=True)])
+    assert torch.equal(ni, parts)                        # tail split / persistent scheduling do not change any row
+    assert torch.equal(nt, torch.cat([m.encode_text(tok[:37], normalize=True), m.encode_text(tok[37:], normalize=True)]))
+    full = float(ClipLoss()(ni, nt, s))
+    assert abs(full - float(ClipLoss()(nt, ni, s))) < 1e-6                     # symmetric in the two modalities
+    from hipops import clip_loss
+    b = 32
+    local = [float(clip_loss(ni[r * b:(r + 1) * b].contiguous(), nt[r * b:(r + 1) * b].contiguous(), ni, nt, float(s), r * b)[0])
+             for r in range(8)]
+    assert abs(np.mean(local) - full) < 2e-5
+    perm = torch.randperm(256, generator=torch.Generator().manual_seed(0)).to(DEV)
+    assert abs(float(ClipLoss()(ni[perm].contiguous(), nt[perm].contiguous(), s)) - full) < 2e-5   # pair order is irrelevant
+
+
 def test_no_cpu_fallback(tiny):
     from openvision_amd._lib import OvhipError
     with pytest.raises(OvhipError):
