@@ -95,7 +95,8 @@ int ov_rowstats(const ov_bf16* x, int64_t ldx, float* rowstats, int64_t rows, in
 
 /* Non-causal, unmasked multi-head self-attention on a packed qkv activation.
  * qkv: [B*L, 3*H*hd] bf16 (q | k | v column blocks, heads contiguous inside each, ld = ld_qkv);
- * out: [B*L, H*hd] bf16 (heads merged, ld = ld_out).  scale multiplies q.k (hd^-0.5).  hd == 64. */
+ * out: [B*L, H*hd] bf16 (heads merged, ld = ld_out).  scale multiplies q.k (hd^-0.5).
+ * hd == 64 takes the tuned kernels; any other multiple of 8 up to 96 (So400m: 72, H/14: 80) a generic one. */
 int ov_attention(const ov_bf16* qkv, int64_t ld_qkv, ov_bf16* out, int64_t ld_out,
                  int B, int L, int H, int hd, float scale, ov_stream_t stream);
 

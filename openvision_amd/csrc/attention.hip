@@ -500,14 +500,174 @@ __global__ __launch_bounds__(DEEP ? 512 : 640, DEEP ? 2 : 3) void attn_fwd_hd64_
     }
 }
 
+// =====================================================================================================
+// Generic head_dim kernel (head_dim 72 = So400m, 80 = H/14; any multiple of 8 up to 96): same S^T / P^T / O^T scheme with
+// the head padded to 96 in LDS (zero columns), 256-key chunks staged through registers, one key tile per step.  A plain,
+// correctness-first variant: these model sizes are not on the benchmark configuration.
+template <int HDP>
+__global__ __launch_bounds__(512, 2) void attn_fwd_generic(const AttnArgs a, int hd) {
+    constexpr int KS = HDP / 16;           // k-steps of S^T = K.Q^T
+    constexpr int DT = HDP / 32;           // 32-row tiles of O^T
+    constexpr int CH = HDP / 8;            // 16-byte chunks per (padded) row
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, nw = nthreads >> 6;
+    const int r = lane & 31, h2 = lane >> 5;
+    const int bh = blockIdx.x, b = bh / a.H, h = bh - b * a.H;
+    const int L = a.L, KC = a.KC;
+    const int HD = a.H * hd;
+    char* ks = smem;                                 // K image: KC rows x HDP*2 bytes
+    char* vs = smem + KC * HDP * 2;                  // V image: DT tiles x KC rows x 64 bytes
+    const ov_bf16* base = a.qkv + (int64_t)b * L * a.ldq + h * hd;
+    const int qt = blockIdx.y * nw + wave;
+    const bool active = qt < a.nqt;
+    const int q0 = qt * 32;
+
+    bf16x8_t qf[KS];
+    {
+        int qrow = q0 + r;
+        qrow = (active && qrow < L) ? qrow : L - 1;
+        const ov_bf16* qp = base + (int64_t)qrow * a.ldq;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int d = 16 * s + 8 * h2;
+            u32x4_t w = {0u, 0u, 0u, 0u};
+            if (d < hd) w = *(const u32x4_t*)(qp + d);
+            qf[s] = __builtin_bit_cast(bf16x8_t, w);
+        }
+    }
+    float m = -INFINITY, lsum = 0.f;
+    f32x16_t o[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[t][i] = 0.f;
+    const int vi = lane & 15, vg = (lane >> 4) & 1;
+    const int v_lane_off = (4 * h2 + (vi >> 2)) * 64 + (16 * vg + 4 * (vi & 3)) * 2;
+
+    for (int kc0 = 0; kc0 < L; kc0 += KC) {
+        if (kc0) __syncthreads();
+        for (int idx = tid; idx < KC * CH; idx += nthreads) {
+            const int row = idx / CH, c = idx - row * CH;
+            u32x4_t kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
+            if (kc0 + row < L && c * 8 < hd) {
+                const ov_bf16* p = base + (int64_t)(kc0 + row) * a.ldq + HD + c * 8;
+                kv = *(const u32x4_t*)p;
+                vv = *(const u32x4_t*)(p + HD);
+            }
+            *(u32x4_t*)(ks + row * (HDP * 2) + c * 16) = kv;
+            *(u32x4_t*)(vs + (c >> 2) * (KC * 64) + row * 64 + (c & 3) * 16) = vv;
+        }
+        __syncthreads();
+        if (!active) continue;
+        const int nk = (L - kc0) < KC ? (L - kc0) : KC;
+        const int ntile = (nk + 31) >> 5;
+        for (int kt = 0; kt < ntile; ++kt) {
+            f32x16_t s;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s[i] = 0.f;
+            const char* kp = ks + (kt * 32 + r) * (HDP * 2) + h2 * 16;
+#pragma unroll
+            for (int st = 0; st < KS; ++st) {
+                const bf16x8_t kf = *(const bf16x8_t*)(kp + st * 32);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], s, 0, 0, 0);
+            }
+            if (kt * 32 + 32 > nk) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = kt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h2;
+                    if (key >= nk) s[i] = -INFINITY;
+                }
+            }
+            float mx = s[0];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s[i]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * a.scale_log2;
+            if (!__all(mx - m <= 8.0f)) {
+                const float mn = fmaxf(m, mx);
+                const float alpha = __builtin_amdgcn_exp2f(m - mn);
+                m = mn;
+                lsum *= alpha;
+#pragma unroll
+                for (int t = 0; t < DT; ++t)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) o[t][i] *= alpha;
+            }
+            const float nm = -m;
+            float ps = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                s[i] = __builtin_amdgcn_exp2f(fmaf(s[i], a.scale_log2, nm));
+                ps += s[i];
+            }
+            lsum += ps;
+            bf16x8_t pf[2];
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                u32x4_t w = {pack_bf16x2(s[8 * st + 0], s[8 * st + 1]), pack_bf16x2(s[8 * st + 2], s[8 * st + 3]),
+                             pack_bf16x2(s[8 * st + 4], s[8 * st + 5]), pack_bf16x2(s[8 * st + 6], s[8 * st + 7])};
+                pf[st] = __builtin_bit_cast(bf16x8_t, w);
+            }
+            const char* vp = vs + kt * 32 * 64 + v_lane_off;
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+#pragma unroll
+                for (int t = 0; t < DT; ++t) {
+                    const char* v0 = vp + t * (KC * 64) + st * 16 * 64;
+                    o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_pair(v0, v0 + 8 * 64), pf[st], o[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (!active) return;
+    const float l = lsum + __shfl_xor(lsum, 32, 64);
+    const float inv = 1.0f / l;
+    const int q = q0 + r;
+    if (q < L) {
+        ov_bf16* op = a.out + ((int64_t)b * L + q) * a.ldo + h * hd + 4 * h2;
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = t * 32 + 8 * g + 4 * h2;
+                if (d < hd) {
+                    const u32x2_t w = {pack_bf16x2(o[t][4 * g] * inv, o[t][4 * g + 1] * inv),
+                                       pack_bf16x2(o[t][4 * g + 2] * inv, o[t][4 * g + 3] * inv)};
+                    *(u32x2_t*)(op + t * 32 + 8 * g) = w;
+                }
+            }
+    }
+}
+
 }  // namespace
 
 extern "C" int ov_attention(const ov_bf16* qkv, int64_t ld_qkv, ov_bf16* out, int64_t ld_out, int B, int L,
                             int H, int hd, float scale, ov_stream_t stream) {
     if (!qkv || !out || B <= 0 || L <= 0 || H <= 0) return OV_ERR_INVALID;
-    if (hd != 64) return OV_ERR_UNSUPPORTED;
+    if (hd <= 0 || hd % 8 || hd > 96) return OV_ERR_UNSUPPORTED;
     if (ld_qkv % 8 || ld_out % 8 || ld_qkv < 3 * H * hd || ld_out < H * hd) return OV_ERR_INVALID;
     if (((uintptr_t)qkv | (uintptr_t)out) & 15) return OV_ERR_INVALID;
+    if (hd != 64) {                                      // So400m (72) / H (80): generic padded-head kernel
+        AttnArgs g;
+        g.qkv = qkv; g.ldq = ld_qkv; g.out = out; g.ldo = ld_out;
+        g.B = B; g.L = L; g.H = H; g.nqt = (L + 31) / 32; g.mode = 0;
+        g.scale_log2 = scale * 1.4426950408889634f;
+        const int lpad = g.nqt * 32;
+        g.KC = lpad < 256 ? lpad : 256;
+        const int nwg = g.nqt < 8 ? g.nqt : 8;
+        const size_t smem = (size_t)g.KC * 96 * 4;       // K (KC x 192 B) + V (3 x KC x 64 B)
+        static bool attr3 = false;
+        if (!attr3) {
+            hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_generic<96>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               160 * 1024);
+            if (e != hipSuccess) return OV_ERR_HIP - (int)e;
+            attr3 = true;
+        }
+        hipLaunchKernelGGL(attn_fwd_generic<96>, dim3((unsigned)(B * H), (unsigned)((g.nqt + nwg - 1) / nwg)), dim3(nwg * 64), smem,
+                           (hipStream_t)stream, g, hd);
+        OV_LAUNCH_CHECK();
+        return OV_OK;
+    }
     AttnArgs a;
     a.qkv = qkv; a.ldq = ld_qkv; a.out = out; a.ldo = ld_out;
     a.B = B; a.L = L; a.H = H;

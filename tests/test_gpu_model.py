@@ -164,6 +164,35 @@ def test_full_size_batch256_properties():
     assert abs(float(ClipLoss()(ni[perm].contiguous(), nt[perm].contiguous(), s)) - full) < 2e-5   # pair order is irrelevant
 
 
+def test_base16_224_against_oracle():
+    """A size the golden files do not hold (B/16@224: 197 tokens, 12 heads, E=512, text width 512): checked against the
+    oracle run here on the CPU in fp32."""
+    from oracle import clip_ref as R
+    cfg = preset("vit-base-patch16-224")
+    sd = synth.make_state_dict(cfg)
+    m = create_model(cfg, device=DEV, state_dict=sd)
+    img, tok = synth.make_images(3, 224, seed=2), synth.make_captions(3, seed=2)
+    ni, nt, s = m(img.to(DEV), tok.to(DEV))
+    ri, rt, rs = R.clip_forward(img, tok, sd, cfg)
+    assert one_minus_cos(ni, ri) < COS_TOL and one_minus_cos(nt, rt) < COS_TOL
+    assert abs(float(ClipLoss()(ni, nt, s)) - float(R.clip_loss(ri, rt, rs))) < 0.05
+
+
+@pytest.mark.parametrize("width,head_width", [(320, 80), (576, 72)])
+def test_head_dims_of_h14_and_so400m(width, head_width):
+    """head_dim 80 (OpenVision H/14) and 72 (So400m, with its 3.7362 MLP ratio -> padded hidden width) against the oracle."""
+    from oracle import clip_ref as R
+    cfg = preset("vit-tiny-patch16-160")
+    cfg["vision_cfg"] = dict(cfg["vision_cfg"], width=width, head_width=head_width, layers=2, mlp_ratio=3.7362)
+    cfg["text_cfg"] = dict(cfg["text_cfg"], width=width, heads=width // head_width, layers=2, mlp_ratio=3.7362)
+    sd = synth.make_state_dict(cfg)
+    m = create_model(cfg, device=DEV, state_dict=sd)
+    img, tok = synth.make_images(3, 160, seed=4), synth.make_captions(3, seed=4)
+    ni, nt, s = m(img.to(DEV), tok.to(DEV))
+    ri, rt, rs = R.clip_forward(img, tok, sd, cfg)
+    assert one_minus_cos(ni, ri) < COS_TOL and one_minus_cos(nt, rt) < COS_TOL
+
+
 def test_no_cpu_fallback(tiny):
     from openvision_amd._lib import OvhipError
     with pytest.raises(OvhipError):

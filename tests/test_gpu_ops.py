@@ -113,6 +113,18 @@ def test_attention(B, L, H_):
     np.testing.assert_allclose(o.numpy(), ref.numpy(), rtol=2e-2, atol=1.5e-2)
 
 
+@pytest.mark.parametrize("B,L,H_,hd", [(2, 257, 3, 80), (1, 101, 2, 72), (1, 300, 1, 80), (2, 80, 4, 72)])
+def test_attention_generic_head_dim(B, L, H_, hd):
+    D = H_ * hd
+    qkv = rnd(B * L, 3 * D, seed=24).to(torch.bfloat16)
+    o = H.attention(qkv.to(DEV), B, L, H_, hd).float().cpu().view(B, L, D)
+    q, k, v = qkv.float().view(B, L, 3 * D).split(D, dim=-1)
+    sp = lambda t: t.reshape(B, L, H_, hd).transpose(1, 2)
+    p = torch.softmax(sp(q) * hd ** -0.5 @ sp(k).transpose(-1, -2), dim=-1)
+    ref = (p @ sp(v)).transpose(1, 2).reshape(B, L, D)
+    np.testing.assert_allclose(o.numpy(), ref.numpy(), rtol=2e-2, atol=1.5e-2)
+
+
 def test_attention_online_softmax_rescale_branch():
     """Force the running max to jump late (a spiked key in the LAST tile) — cdna guide rule 26."""
     B, L, H_ = 1, 257, 1
