@@ -374,18 +374,23 @@ __device__ __forceinline__ void epilogue_2pass(const GemmArgs& g, f32x4_t (&acc)
     }
     const int er = lane >> 3, ec = lane & 7;
     const int n = n0 + wn * 64 + ec * 8;
+    // Every load of the epilogue is issued before the first store: a load placed behind stores would have to wait for
+    // their write acknowledgements (vmcnt is in order), which costs the residual epilogue ~10 us per tile.  Row statistics
+    // of all 8 row groups up front; the residual rows of BOTH passes are fetched (unpredicated, clamped addresses -- a
+    // predicated load makes hipcc serialise the loads behind vmcnt(0)) before any output row is stored.
+    float rmean[8], rrstd[8];
+    if (fold) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int64_t m = m0 + wm * 128 + i * 16 + fr;
+            m = m < g.M ? m : g.M - 1;
+            const float2 st = *(const float2*)(g.rowstats + 2 * m);
+            rmean[i] = st.x; rrstd[i] = st.y;
+        }
+    }
+    u32x4_t vout[2][8];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        float rmean[4], rrstd[4];
-        if (fold) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                int64_t m = m0 + wm * 128 + (h * 4 + i) * 16 + fr;
-                m = m < g.M ? m : g.M - 1;
-                const float2 st = *(const float2*)(g.rowstats + 2 * m);
-                rmean[i] = st.x; rrstd[i] = st.y;
-            }
-        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int ml = i * 16 + fr;
@@ -394,7 +399,7 @@ __device__ __forceinline__ void epilogue_2pass(const GemmArgs& g, f32x4_t (&acc)
                 f32x2_t v01 = f32x2_t{acc[h * 4 + i][j][0], acc[h * 4 + i][j][1]};
                 f32x2_t v23 = f32x2_t{acc[h * 4 + i][j][2], acc[h * 4 + i][j][3]};
                 if (fold) {      // rstd * (acc - mean * colsum) + cvec, as two explicit FMAs (identical in every kernel variant)
-                    const f32x2_t nm = {-rmean[i], -rmean[i]}, rs = {rrstd[i], rrstd[i]};
+                    const f32x2_t nm = {-rmean[h * 4 + i], -rmean[h * 4 + i]}, rs = {rrstd[h * 4 + i], rrstd[h * 4 + i]};
                     v01 = __builtin_elementwise_fma(f32x2_t{sv[j][0], sv[j][1]}, nm, v01);
                     v23 = __builtin_elementwise_fma(f32x2_t{sv[j][2], sv[j][3]}, nm, v23);
                     v01 = __builtin_elementwise_fma(v01, rs, f32x2_t{bv[j][0], bv[j][1]});
@@ -411,36 +416,44 @@ __device__ __forceinline__ void epilogue_2pass(const GemmArgs& g, f32x4_t (&acc)
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // wave-local hand-over (DS ops of one wave are in order)
-        u32x4_t v[8];
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int row = it * 8 + er;
-            v[it] = *(const u32x4_t*)(ep + row * 128 + ((ec ^ (row & 7)) << 4));
+            vout[h][it] = *(const u32x4_t*)(ep + row * 128 + ((ec ^ (row & 7)) << 4));
         }
         if (EPI == OV_EPI_BIAS_RESIDUAL && !resid_folded) {
+            u32x4_t rv[8];
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
-                const int64_t m = m0 + wm * 128 + h * 64 + it * 8 + er;
-                if (m < g.M && n < g.N) {
-                    const int64_t rrow = g.resid_mod ? (m % g.resid_mod) + g.resid_off : m;
-                    const u32x4_t rv = *(const u32x4_t*)(g.R + rrow * g.ldr + n);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        v[it][e] = pack_bf16x2(bf16lo_to_f32(v[it][e]) + bf16lo_to_f32(rv[e]),
-                                               bf16hi_to_f32(v[it][e]) + bf16hi_to_f32(rv[e]));
-                }
+                int64_t m = m0 + wm * 128 + h * 64 + it * 8 + er;
+                m = m < g.M ? m : g.M - 1;
+                const int nc = n < g.N ? n : g.N - 8;
+                const int64_t rrow = g.resid_mod ? (m % g.resid_mod) + g.resid_off : m;
+                rv[it] = *(const u32x4_t*)(g.R + rrow * g.ldr + nc);
             }
+#pragma unroll
+            for (int it = 0; it < 8; ++it)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    vout[h][it][e] = pack_bf16x2(bf16lo_to_f32(vout[h][it][e]) + bf16lo_to_f32(rv[it][e]),
+                                                 bf16hi_to_f32(vout[h][it][e]) + bf16hi_to_f32(rv[it][e]));
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // pass-h reads done before pass-(h+1) writes reuse the image
-        if (h == 0 && drain_loads_before_stores)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile's K-tile 0 has landed; nothing older than the stores
+        // Without residual loads nothing is fetched after this point, so a pass's rows are stored right away (they drain
+        // under the other pass's arithmetic); with them, both passes' loads come first (see above).
+        if (EPI != OV_EPI_BIAS_RESIDUAL || h == 1) {
+            if (drain_loads_before_stores && (EPI == OV_EPI_BIAS_RESIDUAL || h == 0))
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile's K-tile 0 has landed; nothing older than the stores
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int64_t m = m0 + wm * 128 + h * 64 + it * 8 + er;
-            if (m < g.M && n < g.N) {
-                const int64_t orow = g.out_group ? m + m / g.out_group + 1 : m;
-                *(u32x4_t*)(g.C + orow * g.ldc + n) = v[it];
-            }
+            for (int hh = (EPI == OV_EPI_BIAS_RESIDUAL ? 0 : h); hh <= h; ++hh)
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int64_t m = m0 + wm * 128 + hh * 64 + it * 8 + er;
+                    if (m < g.M && n < g.N) {
+                        const int64_t orow = g.out_group ? m + m / g.out_group + 1 : m;
+                        *(u32x4_t*)(g.C + orow * g.ldc + n) = vout[hh][it];
+                    }
+                }
         }
     }
 }
