@@ -17,6 +17,8 @@
  *   ov_l2norm           F.normalize(x, dim=-1)                                model.py:267,284
  *   ov_logits           CLIP.get_logits (scale * img @ txt^T)                 model.py:286-293
  *   ov_clip_loss        ClipLoss.get_logits + cross_entropy both ways         loss.py:102-131
+ *   ov_class_mean_normalize / ov_topk   zero-shot classifier weights, argmax / recall@k ranking   zero_shot_classifier.py:54-57,
+ *                       src/evaluators/proj/image_text/{discriminative_classifier.py:305-323, image_text_retrieval.py:24-87}
  *   ov_tower_*          Transformer.forward (the resblock loop)               transformer.py:355-366, 254-265
  *   ov_vision_* / ov_text_*   VisionTransformer.forward / CLIP.encode_text    transformer.py:609-651, model.py:269-284
  *
@@ -133,6 +135,15 @@ int ov_l2norm(const void* x, int x_dtype, int64_t ldx, float* y, int64_t ldy, in
 /* out[i, j] = scale * <X[i,:], Y[j,:]>  fp32 in/out (CLIP.get_logits: model.py:286-293).  E % 8 == 0. */
 int ov_logits(const float* X, const float* Y, float* out, int64_t ldo, int n1, int n2, int E, float scale,
               ov_stream_t stream);
+
+/* ---- consumers of encode + logits: zero-shot classifier weights and ranking ------------
+ * out[c,:] = normalize(mean_t emb[c*T + t, :])   (open_clip/zero_shot_classifier.py:54-57).  fp32 in/out. */
+int ov_class_mean_normalize(const float* emb, float* out, int C, int T, int E, ov_stream_t stream);
+/* Per-row top-k of x[rows, cols] (fp32): idx_out[rows, k] int64 (and val_out[rows, k], optional), best first;
+ * largest != 0 ranks by value descending (logits), else ascending (distances, as image_text_retrieval.py:44,78 argsort);
+ * ties go to the smaller index.  k <= cols. */
+int ov_topk(const float* x, int64_t ldx, int rows, int cols, int k, int largest, int64_t* idx_out, float* val_out,
+            ov_stream_t stream);
 
 /* Local-strip InfoNCE (ClipLoss with local_loss semantics; world_size 1 = plain ClipLoss).
  *   img, txt      : this rank's L2-normalised embeddings [b, E] fp32

@@ -193,6 +193,52 @@ def test_head_dims_of_h14_and_so400m(width, head_width):
     assert one_minus_cos(ni, ri) < COS_TOL and one_minus_cos(nt, rt) < COS_TOL
 
 
+def test_zero_shot_and_retrieval_evaluators(tiny):
+    """SURVEY.md §8f row 3 on device: classifier weights, top-k (bit-exact indices on the SAME logits) and recall@k
+    against the numpy oracle (oracle/eval_ref.py)."""
+    from oracle import eval_ref as E
+    from openvision_amd import evaluate as ev
+    from openvision_amd.model import logits
+    C_, T_ = 7, 3
+    ctok = synth.make_captions(C_ * T_, seed=12).view(C_, T_, 80).to(DEV)
+    w = ev.build_zero_shot_classifier(tiny, ctok, num_classes_per_batch=4)          # [E, C]
+    emb = tiny.encode_text(ctok.view(-1, 80), normalize=True).cpu().numpy()
+    np.testing.assert_allclose(w.cpu().numpy(), E.zero_shot_classifier(emb, C_, T_), atol=2e-6)
+    img = synth.make_images(12, 160, seed=12).to(DEV)
+    f = tiny.encode_image(img, normalize=True)
+    lg = logits(f, w.T.contiguous(), 100.0)
+    val, idx = ev.topk(lg, 5)
+    ref_idx = np.argsort(-lg.cpu().numpy(), axis=1, kind="stable")[:, :5]
+    assert np.array_equal(idx.cpu().numpy(), ref_idx)                                 # bit-exact index work
+    labels = torch.from_numpy(ref_idx[:, 0].copy())
+    labels[::3] = (labels[::3] + 1) % C_                                              # break every third label
+    assert ev.count_correct(idx[:, 0].cpu(), labels) == E.count_correct(f.cpu().numpy(), w.T.cpu().numpy(), labels.numpy(),
+                                                                         np.ones(12, bool))
+    # retrieval: 12 images, 24 texts (2 per image)
+    ttok = synth.make_captions(24, seed=13).to(DEV)
+    te = tiny.encode_text(ttok, normalize=True)
+    corr = [i // 2 for i in range(24)]
+    got = ev.retrieval_recall(f, te, corr)
+    sim = logits(f, te, 1.0).cpu().numpy()
+    i2t, t2i = E.image_to_text_retrieval_eval(-sim, corr), E.text_to_image_retrieval_eval(-sim, corr)
+    for k in (1, 5, 10):
+        assert abs(got[f"img2txt/Recall@{k}"] - i2t[f"Recall@{k}"]) < 1e-7
+        assert abs(got[f"txt2img/Recall@{k}"] - t2i[f"Recall@{k}"]) < 1e-7
+    # ties: equal values rank by index; smallest-k order on distances
+    x = torch.tensor([[1.0, 3.0, 3.0, 2.0, 3.0], [0.0, 0.0, 0.0, 0.0, 0.0]], device=DEV)
+    assert ev.topk(x, 3)[1].tolist() == [[1, 2, 4], [0, 1, 2]]
+    assert ev.topk(x, 2, largest=False)[1].tolist() == [[0, 3], [0, 1]]
+
+
+def test_checkpoint_dir_to_device(tiny, tmp_path):
+    from openvision_amd import checkpoint as ck
+    cfg = preset("vit-tiny-patch16-160")
+    ck.save_pretrained(tiny, cfg, str(tmp_path), torch_bin=False)
+    m2, _ = ck.from_pretrained(str(tmp_path), device=DEV)
+    img = synth.make_images(2, 160, seed=1).to(DEV)
+    assert torch.equal(m2.encode_image(img), tiny.encode_image(img))
+
+
 def test_no_cpu_fallback(tiny):
     from openvision_amd._lib import OvhipError
     with pytest.raises(OvhipError):
