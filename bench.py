@@ -194,7 +194,7 @@ def main():
                        "gflop_per_pair": round(flops["pair"] / 1e9, 2),
                        "model_tflops_per_gpu": round(flops["pair"] * b * a.steps / dt / 1e12, 1)},
             "loss": round(loss_val, 5),
-            "roofline": {"bound": "mfma", "kernel": f"gemm_bf16_persist<1> (bias + erf-GELU) = vision mlp.c_fc, N={int(Dv * cfg['vision_cfg']['mlp_ratio'])} K={Dv}, "
+            "roofline": {"bound": "mfma", "kernel": f"gemm_bf16_persist<1, true> (LN-folded bias + erf-GELU) = vision mlp.c_fc, N={int(Dv * cfg['vision_cfg']['mlp_ratio'])} K={Dv}, "
                                    f"M={int(rows.value / launches)} rows per launch",
                          "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,

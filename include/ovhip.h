@@ -169,7 +169,7 @@ enum ov_profile_class {
 int ov_profile_enable(unsigned class_mask, int max_records);
 int ov_profile_read(int cls, double* total_ms, int* count, double* total_rows /* sum of launch M, may be NULL */);
 
-/* Diagnostics: device buffer [workgroup][slots][4] of s_memtime stamps written by the persistent GEMM (NULL = off). */
+/* Diagnostics: device buffer [workgroup][slots][8] of s_memtime stamps written by the persistent GEMM (NULL = off). */
 int ov_debug_gemm_stamps(unsigned long long* buf, int slots);
 
 /* ---- tower level (the resblock loop and the two encoders) --------------------------------------- */

@@ -335,71 +335,121 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp(const GemmArgs g) {
 // =====================================================================================================
 // Persistent ping-pong kernel (default).  One workgroup per CU walks a static, XCD-contiguous list of output tiles.
 // On top of the ping-pong main loop above:
-//   * the LAST K-tile of a tile stages K-tile 0 of the NEXT tile into the free LDS buffer, so the next main loop
-//     starts with its operands already on chip (no per-tile prologue latency, no relaunch);
-//   * the epilogue transposes through the 64 KiB buffer the last K-tile occupied (8 KiB per wave, two 64-row passes,
-//     wave-local), leaving the prefetched buffer untouched; its global stores are issued and the next tile's MFMAs
-//     start while they drain, so store bursts of different CUs no longer line up in time;
+//   * the LAST K-tile of a tile stages K-tile 0 of the NEXT tile into the free LDS buffer, and the epilogue opens by
+//     staging K-tile 1 of the next tile into the buffer that has just been consumed -- so every LDS-DMA the next main
+//     loop waits for in its first two K-tiles is OLDER than this epilogue's stores (vmcnt retires in order: a load
+//     issued behind stores waits for their write acknowledgements, several thousand cycles under a store burst);
+//   * the tile's bias / LN-fold column sums / row statistics are LDS-DMA'd into a small parameter block one tile
+//     ahead, so the epilogue starts without a single global-memory round trip;
+//   * the epilogue streams the accumulators through a 2-KiB wave-local transposition image, one 16-row MFMA fragment
+//     row per pass: pack + ds_write of pass i, the row-contiguous ds_read_b128 of pass i, the 16-byte global stores of
+//     pass i-1.  DS operations of one wave execute in order, so the passes need no waits beyond data use;
 //   * the two wave groups re-align for the epilogue (both halves of every SIMD share the VALU work) and re-stagger
 //     by one barrier afterwards.
-template <int EPI>
-__device__ __forceinline__ void epilogue_2pass(const GemmArgs& g, f32x4_t (&acc)[8][4], char* ep, int64_t m0, int n0,
-                                               int wave, int lane, bool drain_loads_before_stores, bool resid_folded) {
+constexpr int IMG_OFF = SMEM_BYTES;                  // 8 wave-local 2-KiB transposition images (16 rows x 64 n bf16)
+constexpr int PRM_OFF = IMG_OFF + 8 * 2048;          // two 4-KiB parameter blocks: bias[256] f32 | colsum[256] f32 | rowstats[256][2] f32
+constexpr int SMEM_PERSIST = PRM_OFF + 2 * 4096;     // 152 KiB of the CU's 160
+
+template <int EPI, bool FOLD>
+__device__ __forceinline__ void epilogue_stream(const GemmArgs& g, f32x4_t (&acc)[8][4], char* img, const char* prm,
+                                                int64_t m0, int n0, int wave, int lane, bool edge) {
     const int wm = wave >> 2, wn = wave & 3;
     const int fr = lane & 15, fq = lane >> 4;
-    float bv[4][4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int nn = n0 + wn * 64 + j * 16 + fq * 4;
-        if (g.bias != nullptr && nn < g.N) {
-            const float4 b4 = *(const float4*)(g.bias + nn);
-            bv[j][0] = b4.x; bv[j][1] = b4.y; bv[j][2] = b4.z; bv[j][3] = b4.w;
-        } else {
-            bv[j][0] = bv[j][1] = bv[j][2] = bv[j][3] = 0.f;
-        }
-    }
-    const bool fold = (EPI != OV_EPI_BIAS_RESIDUAL) && g.colsum != nullptr;
-    float sv[4][4];
-    if (fold) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int nn = n0 + wn * 64 + j * 16 + fq * 4;
-            if (nn < g.N) {
-                const float4 s4 = *(const float4*)(g.colsum + nn);
-                sv[j][0] = s4.x; sv[j][1] = s4.y; sv[j][2] = s4.z; sv[j][3] = s4.w;
-            } else {
-                sv[j][0] = sv[j][1] = sv[j][2] = sv[j][3] = 0.f;
-            }
-        }
-    }
     const int er = lane >> 3, ec = lane & 7;
     const int n = n0 + wn * 64 + ec * 8;
-    // Every load of the epilogue is issued before the first store: a load placed behind stores would have to wait for
-    // their write acknowledgements (vmcnt is in order), which costs the residual epilogue ~10 us per tile.  Row statistics
-    // of all 8 row groups up front; the residual rows of BOTH passes are fetched (unpredicated, clamped addresses -- a
-    // predicated load makes hipcc serialise the loads behind vmcnt(0)) before any output row is stored.
-    float rmean[8], rrstd[8];
-    if (fold) {
+    const bool ncol = n < g.N;
+    // Residual rows (unpredicated, clamped addresses -- a predicated load makes hipcc serialise the loads behind
+    // vmcnt(0)).  Every load of the epilogue is issued before its first store: rows of passes 0-3 now, rows of passes
+    // 4-7 once four accumulator rows have been retired (register room), and only then the first store.
+    u32x4_t rv[8][2];
+    const int nc = ncol ? n : g.N - 8;
+    auto load_resid = [&](int i) {      // inline asm: the waits below are counted by hand (hipcc would use vmcnt(0))
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            int64_t m = m0 + wm * 128 + i * 16 + fr;
-            m = m < g.M ? m : g.M - 1;
-            const float2 st = *(const float2*)(g.rowstats + 2 * m);
-            rmean[i] = st.x; rrstd[i] = st.y;
+        for (int it = 0; it < 2; ++it) {
+            unsigned m = (unsigned)m0 + wm * 128 + i * 16 + it * 8 + er;
+            m = m < (unsigned)g.M ? m : (unsigned)g.M - 1;
+            const unsigned rrow = g.resid_mod ? (m % (unsigned)g.resid_mod) + g.resid_off : m;
+            const ov_bf16* src = g.R + (int64_t)rrow * g.ldr + nc;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rv[i][it]) : "v"(src));
         }
+    };
+    if (EPI == OV_EPI_BIAS_RESIDUAL) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) load_resid(i);
     }
-    u32x4_t vout[2][8];
+    // Parameter block reads are inline asm: as plain LDS loads hipcc orders them behind every LDS-DMA in flight
+    // (s_waitcnt vmcnt(0)), i.e. behind the next tile's K-tile 1 that was issued a moment ago.
+    f32x4_t bq[4], sq[4];
+    f32x2_t stq[8];
+    const unsigned pa = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(prm + (wn * 64 + fq * 4) * 4);
+    const unsigned ra = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(prm + 2048 + (wm * 128 + fr) * 8);
+    // (no branch between a read and its wait: a merge point would make hipcc copy the destination registers early)
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int j = 0; j < 4; ++j) {
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bq[j]) : "v"(pa), "n"(j * 64));
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(sq[j]) : "v"(pa), "n"(1024 + j * 64));
+    }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ml = i * 16 + fr;
+    for (int i = 0; i < 8; ++i) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(stq[i]) : "v"(ra), "n"(i * 128));
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]), "+v"(sq[0]), "+v"(sq[1]), "+v"(sq[2]), "+v"(sq[3]));
+    asm volatile("" : "+v"(stq[0]), "+v"(stq[1]), "+v"(stq[2]), "+v"(stq[3]), "+v"(stq[4]), "+v"(stq[5]), "+v"(stq[6]), "+v"(stq[7]));
+    const bool has_bias = g.bias != nullptr;
+    float bv[4][4], sv[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            bv[j][e] = has_bias ? bq[j][e] : 0.f;
+            sv[j][e] = FOLD ? sq[j][e] : 0.f;
+        }
+    char* const wr = img + fr * 128 + (fq & 1) * 8;
+    const int wsw = fr & 7;
+    const char* const rd = img + er * 128 + ((ec ^ er) << 4);       // rows er and er + 8 share (row & 7)
+    u32x4_t vo[8][2];
+    auto put = [&](int i) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            u32x4_t o = vo[i][it];
+            if (EPI == OV_EPI_BIAS_RESIDUAL) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    o[e] = pack_bf16x2(bf16lo_to_f32(o[e]) + bf16lo_to_f32(rv[i][it][e]),
+                                       bf16hi_to_f32(o[e]) + bf16hi_to_f32(rv[i][it][e]));
+            }
+            const unsigned m = (unsigned)m0 + wm * 128 + i * 16 + it * 8 + er;
+            if (m < (unsigned)g.M && ncol) {
+                const unsigned orow = g.out_group ? m + m / (unsigned)g.out_group + 1 : m;
+                *(u32x4_t*)(g.C + (int64_t)orow * g.ldc + n) = o;
+            }
+        }
+    };
+    // vmcnt is counted by hand around the asm residual loads: `edge` tiles issue fewer than 2 stores per pass, so they
+    // fall back to a full drain
+    auto wait_resid = [&](int i0, int i1, int younger) {
+        if (edge) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (younger == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+#pragma unroll
+        for (int k = i0; k < i1; ++k) asm volatile("" : "+v"(rv[k][0]), "+v"(rv[k][1]));
+    };
+#pragma unroll
+    for (int i = 0; i <= 8; ++i) {
+        if (EPI == OV_EPI_BIAS_RESIDUAL && i == 4) {
+#pragma unroll
+            for (int k = 4; k < 8; ++k) load_resid(k);
+        }
+        if (i < 8) {
+            f32x2_t nm = {0.f, 0.f}, rs = {1.f, 1.f};
+            if (FOLD) {
+                nm = f32x2_t{-stq[i][0], -stq[i][0]};
+                rs = f32x2_t{stq[i][1], stq[i][1]};
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                f32x2_t v01 = f32x2_t{acc[h * 4 + i][j][0], acc[h * 4 + i][j][1]};
-                f32x2_t v23 = f32x2_t{acc[h * 4 + i][j][2], acc[h * 4 + i][j][3]};
-                if (fold) {      // rstd * (acc - mean * colsum) + cvec, as two explicit FMAs (identical in every kernel variant)
-                    const f32x2_t nm = {-rmean[h * 4 + i], -rmean[h * 4 + i]}, rs = {rrstd[h * 4 + i], rrstd[h * 4 + i]};
+                f32x2_t v01 = f32x2_t{acc[i][j][0], acc[i][j][1]};
+                f32x2_t v23 = f32x2_t{acc[i][j][2], acc[i][j][3]};
+                if (FOLD) {      // rstd * (acc - mean * colsum) + cvec, as two explicit FMAs (identical in every kernel variant)
                     v01 = __builtin_elementwise_fma(f32x2_t{sv[j][0], sv[j][1]}, nm, v01);
                     v23 = __builtin_elementwise_fma(f32x2_t{sv[j][2], sv[j][3]}, nm, v23);
                     v01 = __builtin_elementwise_fma(v01, rs, f32x2_t{bv[j][0], bv[j][1]});
@@ -410,57 +460,33 @@ __device__ __forceinline__ void epilogue_2pass(const GemmArgs& g, f32x4_t (&acc)
                 }
                 if (EPI == OV_EPI_BIAS_GELU_ERF) { v01 = gelu_erf_f2(v01); v23 = gelu_erf_f2(v23); }
                 if (EPI == OV_EPI_BIAS_GELU_TANH) { v01 = gelu_tanh_f2(v01); v23 = gelu_tanh_f2(v23); }
-                u32x2_t pk = {pack_bf16x2(v01[0], v01[1]), pack_bf16x2(v23[0], v23[1])};
-                const int c = j * 2 + (fq >> 1);
-                *(u32x2_t*)(ep + ml * 128 + ((c ^ (ml & 7)) << 4) + (fq & 1) * 8) = pk;
+                const u32x2_t pk = {pack_bf16x2(v01[0], v01[1]), pack_bf16x2(v23[0], v23[1])};
+                *(u32x2_t*)(wr + (((j * 2 + (fq >> 1)) ^ wsw) << 4)) = pk;
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // wave-local hand-over (DS ops of one wave are in order)
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int row = it * 8 + er;
-            vout[h][it] = *(const u32x4_t*)(ep + row * 128 + ((ec ^ (row & 7)) << 4));
+        // rows of pass i-1 (read one pass ago) leave while pass i is in the LDS pipe; with residual rows the first
+        // four passes are held back until the second half of the residual loads is out
+        if (EPI == OV_EPI_BIAS_RESIDUAL) {
+            // in flight behind the rows waited for: i == 4: rows of passes 4-7 (8 loads); later: the remaining row loads
+            // plus the stores of all earlier passes = 14 every time
+            if (i == 4) { wait_resid(0, 4, 8); put(0); put(1); put(2); put(3); }
+            else if (i > 4) { wait_resid(i - 1, i, 14); put(i - 1); }
+        } else if (i > 0) {
+            put(i - 1);
         }
-        if (EPI == OV_EPI_BIAS_RESIDUAL && !resid_folded) {
-            u32x4_t rv[8];
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                int64_t m = m0 + wm * 128 + h * 64 + it * 8 + er;
-                m = m < g.M ? m : g.M - 1;
-                const int nc = n < g.N ? n : g.N - 8;
-                const int64_t rrow = g.resid_mod ? (m % g.resid_mod) + g.resid_off : m;
-                rv[it] = *(const u32x4_t*)(g.R + rrow * g.ldr + nc);
-            }
-#pragma unroll
-            for (int it = 0; it < 8; ++it)
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    vout[h][it][e] = pack_bf16x2(bf16lo_to_f32(vout[h][it][e]) + bf16lo_to_f32(rv[it][e]),
-                                                 bf16hi_to_f32(vout[h][it][e]) + bf16hi_to_f32(rv[it][e]));
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // pass-h reads done before pass-(h+1) writes reuse the image
-        // Without residual loads nothing is fetched after this point, so a pass's rows are stored right away (they drain
-        // under the other pass's arithmetic); with them, both passes' loads come first (see above).
-        if (EPI != OV_EPI_BIAS_RESIDUAL || h == 1) {
-            if (drain_loads_before_stores && (EPI == OV_EPI_BIAS_RESIDUAL || h == 0))
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile's K-tile 0 has landed; nothing older than the stores
-#pragma unroll
-            for (int hh = (EPI == OV_EPI_BIAS_RESIDUAL ? 0 : h); hh <= h; ++hh)
-#pragma unroll
-                for (int it = 0; it < 8; ++it) {
-                    const int64_t m = m0 + wm * 128 + hh * 64 + it * 8 + er;
-                    if (m < g.M && n < g.N) {
-                        const int64_t orow = g.out_group ? m + m / g.out_group + 1 : m;
-                        *(u32x4_t*)(g.C + orow * g.ldc + n) = vout[hh][it];
-                    }
-                }
+        if (i < 8) {
+            vo[i][0] = *(const u32x4_t*)(rd);
+            vo[i][1] = *(const u32x4_t*)(rd + 1024);
         }
     }
 }
 
-template <int EPI>
+template <int V> struct IntC { static constexpr int value = V; };
+struct TileSrc { const ov_bf16* a0; const ov_bf16* a1; const ov_bf16* w0; const ov_bf16* w1; };   // per-lane staging sources
+
+template <int EPI, bool FOLD>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist(const GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
+    __shared__ __attribute__((aligned(16))) char smem[SMEM_PERSIST];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -478,37 +504,54 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist(const GemmArgs 
 
     const int srow = tid >> 2;
     const int schunk = (tid & 3) ^ swz4(srow);
-    const ov_bf16* asrc[2];
-    const ov_bf16* wsrc[2];
-    const ov_bf16* nasrc[2];
-    const ov_bf16* nwsrc[2];
+    TileSrc cur, nxt;
     int64_t m0, nm0 = 0;
     int n0, nn0 = 0;
-    auto set_tile = [&](int trel, const ov_bf16* (&as)[2], const ov_bf16* (&ws)[2], int64_t& mm, int& nn) {
+    auto set_tile = [&](int trel, TileSrc& ts, int64_t& mm, int& nn) {
         const int wg = xstart + trel;
         const int tm = wg / g.tiles_n, tn = wg - tm * g.tiles_n;
         mm = (int64_t)tm * BM;
         nn = tn * BN;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int64_t ar = mm + i * 128 + srow;
-            ar = ar < g.M ? ar : g.M - 1;
-            int wr = nn + i * 128 + srow;
-            wr = wr < g.N ? wr : g.N - 1;
-            as[i] = g.A + ar * g.lda + schunk * 8;
-            ws[i] = g.W + (int64_t)wr * g.ldw + schunk * 8;
+        int64_t ar0 = mm + srow, ar1 = mm + 128 + srow;
+        ar0 = ar0 < g.M ? ar0 : g.M - 1;
+        ar1 = ar1 < g.M ? ar1 : g.M - 1;
+        int wr0 = nn + srow, wr1 = nn + 128 + srow;
+        wr0 = wr0 < g.N ? wr0 : g.N - 1;
+        wr1 = wr1 < g.N ? wr1 : g.N - 1;
+        ts.a0 = g.A + ar0 * g.lda + schunk * 8;
+        ts.a1 = g.A + ar1 * g.lda + schunk * 8;
+        ts.w0 = g.W + (int64_t)wr0 * g.ldw + schunk * 8;
+        ts.w1 = g.W + (int64_t)wr1 * g.ldw + schunk * 8;
+    };
+    auto advance = [&](TileSrc& ts) { ts.a0 += BK; ts.a1 += BK; ts.w0 += BK; ts.w1 += BK; };
+    char* const sbase = smem + wave * 1024;
+    // piece p of the K-tile `ts` points at -> LDS buffer at byte offset boff.  Pieces 2, 3 are the k 32-63 half: the +64 B
+    // ride in the instruction offset, which the DMA also adds to its LDS address (hence the -64 on M0).
+    auto stage_piece = [&](const TileSrc& ts, int boff, int p) {
+        char* dst = sbase + boff + p * PIECE_BYTES;
+        const ov_bf16* s0 = (p & 1) ? ts.w0 : ts.a0;
+        const ov_bf16* s1 = (p & 1) ? ts.w1 : ts.a1;
+        if (p >> 1) {
+            __builtin_amdgcn_global_load_lds((gptr_t)s0, (lptr_t)(dst - 64), 16, 64, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)s1, (lptr_t)(dst + 8192 - 64), 16, 64, 0);
+        } else {
+            __builtin_amdgcn_global_load_lds((gptr_t)s0, (lptr_t)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)s1, (lptr_t)(dst + 8192), 16, 0, 0);
         }
     };
-    char* const sbase = smem + wave * 1024;
-    auto stage_piece = [&](const ov_bf16* const (&as)[2], const ov_bf16* const (&ws)[2], int buf, int j, int k0) {
-        char* dst = sbase + buf * STAGE_BYTES + j * PIECE_BYTES;
-        const int kk = k0 + (j >> 1) * 32;
-        if (j & 1) {
-            __builtin_amdgcn_global_load_lds((gptr_t)(ws[0] + kk), (lptr_t)dst, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(ws[1] + kk), (lptr_t)(dst + 8192), 16, 0, 0);
-        } else {
-            __builtin_amdgcn_global_load_lds((gptr_t)(as[0] + kk), (lptr_t)dst, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(as[1] + kk), (lptr_t)(dst + 8192), 16, 0, 0);
+    // tile parameters -> LDS block `slot` (lane-linear DMA images): wave 0 the 256 bias values, wave 1 the column sums,
+    // every wave 32 rows of {mean, rstd} (dword granules, so a clamped row never shifts its neighbours)
+    auto stage_params = [&](int slot, int64_t mm, int nn) {
+        char* dst = smem + PRM_OFF + slot * 4096;
+        int c = nn + lane * 4;
+        c = c + 4 <= g.N ? c : g.N - 4;
+        if (wave == 0 && g.bias != nullptr) __builtin_amdgcn_global_load_lds((gptr_t)(g.bias + c), (lptr_t)dst, 16, 0, 0);
+        if (FOLD) {
+            if (wave == 1) __builtin_amdgcn_global_load_lds((gptr_t)(g.colsum + c), (lptr_t)(dst + 1024), 16, 0, 0);
+            const int f = wave * 64 + lane;
+            int64_t r = mm + (f >> 1);
+            r = r < g.M ? r : g.M - 1;
+            __builtin_amdgcn_global_load_lds((gptr_t)(g.rowstats + 2 * r + (f & 1)), (lptr_t)(dst + 2048 + wave * 256), 4, 0, 0);
         }
     };
 
@@ -517,85 +560,133 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist(const GemmArgs 
     const int lsw = (fq ^ swz4(fr)) << 4;
     const int a_lane = (wm * 128 + fr) * 64 + lsw;
     const int w_lane = PIECE_BYTES + (wn * 64 + fr) * 64 + lsw;
-    const int nt = g.K / BK;
-    set_tile(tcur, asrc, wsrc, m0, n0);
+    const int nt = g.K / BK;                                       // >= 3 (launcher)
+    set_tile(tcur, cur, m0, n0);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) stage_piece(asrc, wsrc, 0, j, 0);
+    for (int j = 0; j < 4; ++j) stage_piece(cur, 0, j);
+    advance(cur);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) stage_piece(cur, STAGE_BYTES, j);
+    advance(cur);                                                  // invariant at tile start: `cur` points at K-tile 2
+    stage_params(0, m0, n0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (wm == 1) __builtin_amdgcn_s_barrier();                     // stagger the lower wave group by one interval
 
-    int par = 0;
+    int cb = 0, pslot = 0;   // LDS buffer (byte offset) of the K-tile being consumed; parameter block of the current tile
+    bool strict = true;      // K-tile 1 wait of this tile must not count on 16 younger stores (first tile / after an edge tile)
+    bool has_next = false;
     int titer = 0;
     auto stamp = [&](int k) {
         if (g.stamps != nullptr && tid == 0 && titer < g.stamp_slots)
-            g.stamps[((size_t)bid * g.stamp_slots + titer) * 4 + k] = __builtin_amdgcn_s_memtime();
+            g.stamps[((size_t)bid * g.stamp_slots + titer) * 8 + k] = __builtin_amdgcn_s_memtime();
+    };
+    f32x4_t acc[8][4];
+    bf16x8_t af[4], wf[4];
+    // One K-tile = four phases (k-half x m-half), each a LOAD segment (LDS fragment reads, one piece of the K-tile after
+    // next by LDS-DMA) and a COMPUTE segment (16 MFMAs) between barriers.  KIND selects what is staged and waited for, at
+    // compile time, so the steady-state body carries no branch:
+    //   0: K-tile 0 of a tile -- K-tile 1 is already in flight (previous epilogue / prologue), nothing is staged; its
+    //      wait leaves the previous epilogue's 16 stores outstanding;   1: K-tile 1 -- stages K-tile 2, first wait at p 3;
+    //   2: steady state;   3: last K-tile -- stages K-tile 0 of the next tile, if any.
+    auto ktile = [&](auto kind) {
+        constexpr int KIND = decltype(kind)::value;
+        const char* s = smem + cb;
+        const int nb = cb ^ STAGE_BYTES;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int kh = p >> 1, mh = p & 1;
+            const char* sp = s + kh * (2 * PIECE_BYTES);
+            if (mh == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wf[j] = *(const bf16x8_t*)(sp + w_lane + j * 1024);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8_t*)(sp + a_lane + (mh * 4 + i) * 1024);
+            if (KIND == 1 || KIND == 2) stage_piece(cur, nb, p);
+            if (KIND == 3) { if (has_next) stage_piece(nxt, nb, p); }
+            if (p & 1) {
+                if (KIND == 0) {
+                    if (p == 3) {
+                        if (strict) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                    }
+                } else if (KIND == 1) {
+                    if (p == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                } else if (KIND == 2) {
+                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                } else {
+                    if (has_next) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else if (p == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[mh * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[mh * 4 + i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
     };
     for (;;) {
         stamp(0);
         const int tnext = tcur + nper;
-        const bool has_next = tnext < xcnt;
-        if (has_next) set_tile(tnext, nasrc, nwsrc, nm0, nn0);
-
-        f32x4_t acc[8][4];
+        has_next = tnext < xcnt;
+        if (has_next) set_tile(tnext, nxt, nm0, nn0);
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-        bf16x8_t af[4], wf[4];
-        for (int t = 0; t < nt; ++t) {
-            const char* s = smem + ((par + t) & 1) * STAGE_BYTES;
-            const bool last = (t == nt - 1);
-            const bool more = !last || has_next;
-            const int nbuf = (par + t + 1) & 1;
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int kh = p >> 1, mh = p & 1;
-                const char* sp = s + kh * (2 * PIECE_BYTES);
-                if (mh == 0) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) wf[j] = *(const bf16x8_t*)(sp + w_lane + j * 1024);
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8_t*)(sp + a_lane + (mh * 4 + i) * 1024);
-                if (more) {
-                    if (!last) stage_piece(asrc, wsrc, nbuf, p, (t + 1) * BK);
-                    else stage_piece(nasrc, nwsrc, nbuf, p, 0);
-                }
-                if (p & 1) {
-                    // K-tile 0 of every tile was fully waited for (prologue / previous epilogue): no wait at t == 0, p == 1
-                    if (more) { if (t > 0 || p == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
-                    else if (p == 1 && t > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[mh * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[mh * 4 + i][j], 0, 0, 0);
-                __builtin_amdgcn_s_setprio(0);
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
+        ktile(IntC<0>{});
+        cb ^= STAGE_BYTES;
+        stamp(4);
+        ktile(IntC<1>{});
+        cb ^= STAGE_BYTES;
+        advance(cur);
+        stamp(5);
+        for (int t = 2; t < nt - 1; ++t) {
+            ktile(IntC<2>{});
+            cb ^= STAGE_BYTES;
+            advance(cur);
+            if (g.stamps != nullptr) {                             // diagnostics only: where inside the main loop the time goes
+                if (t == 3) stamp(6);
+                else if (t == 7) stamp(7);
             }
         }
+        ktile(IntC<3>{});
         stamp(1);
         if (wm == 0) __builtin_amdgcn_s_barrier();                 // re-align: every wave is past its last COMPUTE segment
         stamp(2);
-        char* ep = smem + ((par + nt - 1) & 1) * STAGE_BYTES + wave * 8192;
-        epilogue_2pass<EPI>(g, acc, ep, m0, n0, wave, lane, has_next, false);
+        if (has_next) {
+            // the buffer of the last K-tile is free: K-tile 1 of the next tile and its parameters go out ahead of the stores
+            advance(nxt);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) stage_piece(nxt, cb, j);
+            advance(nxt);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // K-tile 0 of the next tile (issued a K-tile ago) has landed
+            stage_params(pslot ^ 1, nm0, nn0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const bool edge = (m0 + BM > g.M) || (n0 + BN > g.N);      // an edge tile issues fewer than 16 stores per wave
+        epilogue_stream<EPI, FOLD>(g, acc, smem + IMG_OFF + wave * 2048, smem + PRM_OFF + pslot * 4096, m0, n0, wave, lane, edge);
         stamp(3);
         ++titer;
         if (!has_next) break;
+        strict = edge;
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();                               // next K-tile 0 visible to all; epilogue image is dead
+        __builtin_amdgcn_s_barrier();                               // next K-tile 0 visible to all
         if (wm == 1) __builtin_amdgcn_s_barrier();                  // re-stagger
-        par = (par + nt) & 1;
-        asrc[0] = nasrc[0]; asrc[1] = nasrc[1]; wsrc[0] = nwsrc[0]; wsrc[1] = nwsrc[1];
+        cb ^= STAGE_BYTES;
+        pslot ^= 1;
+        cur = nxt;
         m0 = nm0; n0 = nn0;
         tcur = tnext;
     }
@@ -633,14 +724,18 @@ int launch(GemmArgs a, hipStream_t st) {
     int var = gemm_variant();
     const int nwg = a.tiles_m * a.tiles_n;
     // fewer tiles than CUs (pooled heads, the tower's tail images): persistence buys nothing, use the plain launch
-    if (var == 0 && nwg < num_cus()) var = 2;
+    if (var == 0 && (nwg < num_cus() || a.K < 3 * BK)) var = 2;
     if (var == 1) {
         hipLaunchKernelGGL(gemm_bf16_256x256<EPI>, dim3(nwg), dim3(NTHREADS), 0, st, a);
     } else if (var == 2) {
         hipLaunchKernelGGL(gemm_bf16_pp<EPI>, dim3(nwg), dim3(NTHREADS), 0, st, a);
     } else {
         const int ncu = num_cus();
-        hipLaunchKernelGGL(gemm_bf16_persist<EPI>, dim3(nwg < ncu ? nwg : ncu), dim3(NTHREADS), 0, st, a);
+        const dim3 grid(nwg < ncu ? nwg : ncu), blk(NTHREADS);
+        if (EPI != OV_EPI_BIAS_RESIDUAL && a.colsum != nullptr)
+            hipLaunchKernelGGL((gemm_bf16_persist<EPI, EPI != OV_EPI_BIAS_RESIDUAL>), grid, blk, 0, st, a);
+        else
+            hipLaunchKernelGGL((gemm_bf16_persist<EPI, false>), grid, blk, 0, st, a);
     }
     OV_LAUNCH_CHECK();
     return OV_OK;
@@ -663,7 +758,7 @@ extern "C" int ov_gemm(const ov_bf16* A, int64_t lda, const ov_bf16* W, int64_t 
     if (out_group < 0 || resid_mod < 0 || resid_off < 0) return OV_ERR_INVALID;
     const int64_t tiles_m = (M + BM - 1) / BM;
     const int64_t tiles_n = (N + BN - 1) / BN;
-    if (tiles_m * tiles_n > 0x7fffffffLL) return OV_ERR_UNSUPPORTED;
+    if (tiles_m * tiles_n > 0x7fffffffLL || M > 0x7fff0000LL) return OV_ERR_UNSUPPORTED;    // 32-bit row indices in the kernels
     GemmArgs a{A, W, bias, C, R, lda, ldw, ldc, ldr, M, N, K, (int)tiles_m, (int)tiles_n,
                out_group, resid_mod, resid_off, g_colsum, g_rowstats, g_stamps, g_stamp_slots};
     hipStream_t st = (hipStream_t)stream;
@@ -677,7 +772,7 @@ extern "C" int ov_gemm(const ov_bf16* A, int64_t lda, const ov_bf16* W, int64_t 
 }
 
 // Diagnostics: when set, the persistent kernel's thread 0 of every workgroup records s_memtime at tile start / main-loop
-// end / after the re-align barrier / epilogue end into buf[block][slot][4] (slot = tile iteration < slots).  NULL = off.
+// end / after the re-align barrier / epilogue end / end of K-tiles 0, 1, 3, 7 into buf[block][slot][8] (slot = tile iteration < slots).  NULL = off.
 extern "C" int ov_debug_gemm_stamps(unsigned long long* buf, int slots) {
     g_stamps = buf;
     g_stamp_slots = buf ? slots : 0;

@@ -15,15 +15,24 @@ for name, (N, K, epi) in cases.items():
     out = x.clone() if epi == 3 else torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     for _ in range(3):
         H.gemm(a, w, bias, epi=epi, resid=out if epi == 3 else None, out=out)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        H.gemm(a, w, bias, epi=epi, resid=out if epi == 3 else None, out=out)
+    e1.record(); torch.cuda.synchronize()
+    print(f"{name}: avg of 20 launches {e0.elapsed_time(e1) * 50:.1f} us = {2 * M * N * K / (e0.elapsed_time(e1) / 20 * 1e-3) / 1e12:.0f} TFLOP/s")
+    if os.environ.get("STAMPS", "1") == "0":
+        continue
     slots = 20
-    buf = torch.zeros(256 * slots * 4, dtype=torch.int64, device="cuda")
+    SW = int(os.environ.get('STAMP_W', '8'))
+    buf = torch.zeros(256 * slots * SW, dtype=torch.int64, device="cuda")
     lib.ov_debug_gemm_stamps(_lib.ptr(buf), slots)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); H.gemm(a, w, bias, epi=epi, resid=out if epi == 3 else None, out=out); e1.record()
     torch.cuda.synchronize()
     lib.ov_debug_gemm_stamps(None, 0)
-    st = buf.cpu().numpy().reshape(256, slots, 4).astype(np.float64)
+    st = buf.cpu().numpy().reshape(256, slots, SW).astype(np.float64)
     ntile = int((st[:, :, 0] > 0).sum(1).max())
     st = st[:, :ntile]
     t0 = st[:, 0, 0].min()
@@ -34,4 +43,10 @@ for name, (N, K, epi) in cases.items():
           f"(min {main.min():.2f} max {main.max():.2f}) = {main.mean()/(K//64):.3f} us/K-tile; align {align.mean():.2f}; "
           f"epilogue {epi_t.mean():.2f} (min {epi_t.min():.2f} max {epi_t.max():.2f}); restart gap {gap.mean():.2f}; "
           f"first start spread {us(st[:,0,0].max()-t0):.2f}, last end spread {us(st[:,-1,3].max()-st[:,-1,3].min()):.2f}")
+    if SW < 8:
+        continue
+    k0 = us(st[:, :, 4] - st[:, :, 0]); k1 = us(st[:, :, 5] - st[:, :, 4]); k23 = us(st[:, :, 6] - st[:, :, 5]) / 2
+    k47 = us(st[:, :, 7] - st[:, :, 6]) / 4; rest = us(st[:, :, 1] - st[:, :, 7]) / max(K // 64 - 8, 1)
+    print(f"   K-tile us: t0 {k0[:,1:].mean():.3f} (first tile {k0[:,0].mean():.3f}) t1 {k1[:,1:].mean():.3f} t2-3 {k23[:,1:].mean():.3f} "
+          f"t4-7 {k47[:,1:].mean():.3f} rest {rest[:,1:].mean():.3f}")
     print("   per-tile main (CU 0):", np.round(main[0], 2), " epilogue (CU 0):", np.round(epi_t[0], 2))
