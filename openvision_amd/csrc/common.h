@@ -93,6 +93,31 @@ __device__ __forceinline__ f32x2_t gelu_erf_f2(f32x2_t x) {
     const f32x2_t phi = __builtin_elementwise_fma(xc, q, f32x2_t{0.5f, 0.5f});
     return x * phi;
 }
+// Two pairs at once, the two Horner chains interleaved statement by statement: back-to-back dependent v_pk_fma_f32
+// cost a wait state each (hipcc pads them with s_nop), two independent chains issue without gaps.  Same arithmetic.
+__device__ __forceinline__ void gelu_erf_f2x2(f32x2_t& x, f32x2_t& y) {
+    const f32x2_t xc = {__builtin_amdgcn_fmed3f(x[0], -4.0f, 4.0f), __builtin_amdgcn_fmed3f(x[1], -4.0f, 4.0f)};
+    const f32x2_t yc = {__builtin_amdgcn_fmed3f(y[0], -4.0f, 4.0f), __builtin_amdgcn_fmed3f(y[1], -4.0f, 4.0f)};
+    const f32x2_t u = xc * xc, v = yc * yc;
+    f32x2_t q = __builtin_elementwise_fma(u, f32x2_t{-1.832668545e-09f, -1.832668545e-09f}, f32x2_t{1.370619420e-07f, 1.370619420e-07f});
+    f32x2_t r = __builtin_elementwise_fma(v, f32x2_t{-1.832668545e-09f, -1.832668545e-09f}, f32x2_t{1.370619420e-07f, 1.370619420e-07f});
+    q = __builtin_elementwise_fma(q, u, f32x2_t{-4.476110938e-06f, -4.476110938e-06f});
+    r = __builtin_elementwise_fma(r, v, f32x2_t{-4.476110938e-06f, -4.476110938e-06f});
+    q = __builtin_elementwise_fma(q, u, f32x2_t{8.535522916e-05f, 8.535522916e-05f});
+    r = __builtin_elementwise_fma(r, v, f32x2_t{8.535522916e-05f, 8.535522916e-05f});
+    q = __builtin_elementwise_fma(q, u, f32x2_t{-1.079715229e-03f, -1.079715229e-03f});
+    r = __builtin_elementwise_fma(r, v, f32x2_t{-1.079715229e-03f, -1.079715229e-03f});
+    q = __builtin_elementwise_fma(q, u, f32x2_t{9.774306659e-03f, 9.774306659e-03f});
+    r = __builtin_elementwise_fma(r, v, f32x2_t{9.774306659e-03f, 9.774306659e-03f});
+    q = __builtin_elementwise_fma(q, u, f32x2_t{-6.634450104e-02f, -6.634450104e-02f});
+    r = __builtin_elementwise_fma(r, v, f32x2_t{-6.634450104e-02f, -6.634450104e-02f});
+    q = __builtin_elementwise_fma(q, u, f32x2_t{3.989241898e-01f, 3.989241898e-01f});
+    r = __builtin_elementwise_fma(r, v, f32x2_t{3.989241898e-01f, 3.989241898e-01f});
+    const f32x2_t phx = __builtin_elementwise_fma(xc, q, f32x2_t{0.5f, 0.5f});
+    const f32x2_t phy = __builtin_elementwise_fma(yc, r, f32x2_t{0.5f, 0.5f});
+    x = x * phx;
+    y = y * phy;
+}
 __device__ __forceinline__ f32x2_t gelu_tanh_f2(f32x2_t x) {
     const f32x2_t u = x * 0.7978845608028654f * __builtin_elementwise_fma(x * 0.044715f, x, f32x2_t{1.0f, 1.0f});
     const f32x2_t a = u * -2.8853900817779268f;

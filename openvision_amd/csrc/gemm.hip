@@ -97,7 +97,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4_t (&acc)[
                 v01 += f32x2_t{bv[j][0], bv[j][1]};
                 v23 += f32x2_t{bv[j][2], bv[j][3]};
             }
-            if (EPI == OV_EPI_BIAS_GELU_ERF) { v01 = gelu_erf_f2(v01); v23 = gelu_erf_f2(v23); }
+            if (EPI == OV_EPI_BIAS_GELU_ERF) gelu_erf_f2x2(v01, v23);
             if (EPI == OV_EPI_BIAS_GELU_TANH) { v01 = gelu_tanh_f2(v01); v23 = gelu_tanh_f2(v23); }
             u32x2_t p = {pack_bf16x2(v01[0], v01[1]), pack_bf16x2(v23[0], v23[1])};
             const int c = j * 2 + (fq >> 1);
@@ -458,7 +458,7 @@ __device__ __forceinline__ void epilogue_stream(const GemmArgs& g, f32x4_t (&acc
                     v01 += f32x2_t{bv[j][0], bv[j][1]};
                     v23 += f32x2_t{bv[j][2], bv[j][3]};
                 }
-                if (EPI == OV_EPI_BIAS_GELU_ERF) { v01 = gelu_erf_f2(v01); v23 = gelu_erf_f2(v23); }
+                if (EPI == OV_EPI_BIAS_GELU_ERF) gelu_erf_f2x2(v01, v23);
                 if (EPI == OV_EPI_BIAS_GELU_TANH) { v01 = gelu_tanh_f2(v01); v23 = gelu_tanh_f2(v23); }
                 const u32x2_t pk = {pack_bf16x2(v01[0], v01[1]), pack_bf16x2(v23[0], v23[1])};
                 *(u32x2_t*)(wr + (((j * 2 + (fq >> 1)) ^ wsw) << 4)) = pk;
