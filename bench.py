@@ -27,6 +27,7 @@ import torch                      # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0         # dense MFMA bf16, /opt/skills/guides/MI355X_MICROARCH.md (chip-level parameters)
+PEAK_HBM_GBS = 8000.0             # HBM3E, same guide
 PROF_CLASSES = {"ln": 0, "gemm_qkv": 1, "attention": 2, "gemm_out": 3, "gemm_fc": 4, "gemm_proj": 5, "gemm_fc_text": 6}
 
 
@@ -40,6 +41,28 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--breakdown", action="store_true", help="extra untimed step timing every kernel class")
     return ap.parse_args()
+
+
+def class_work(cfg, b):
+    """Algorithmic work of one step per profiler class: FLOP for the MFMA-bound classes, HBM bytes for the
+    row-statistics launches.  Rows of the tail image (side stream, overlapped) are left out, as in the class times."""
+    v, t = cfg["vision_cfg"], cfg["text_cfg"]
+    g = v["image_size"] // v["patch_size"]
+    Lv, Dv, Dt, T = g * g + 1, v["width"], t["width"], t["context_length"]
+    Fv, Ft = int(Dv * v["mlp_ratio"]), int(Dt * t.get("mlp_ratio", 4.0))
+    vl, tl = v["layers"], t["layers"]
+    hdv = v.get("head_width", 64)
+    hv, ht = Dv // hdv, t["heads"]
+    Mv, Mt = b * Lv, b * T
+    return {
+        "ln": ("hbm", 2.0 * (2 * vl * Mv * Dv + 2 * tl * Mt * Dt)),                       # each launch reads the bf16 stream once
+        "gemm_qkv": ("mfma", 2.0 * (vl * Mv * 3 * Dv * Dv + tl * Mt * 3 * Dt * Dt)),
+        "attention": ("mfma", 4.0 * (vl * b * hv * Lv * Lv * hdv + tl * b * ht * T * T * (Dt // ht))),
+        "gemm_out": ("mfma", 2.0 * (vl * Mv * Dv * Dv + tl * Mt * Dt * Dt)),
+        "gemm_fc": ("mfma", 2.0 * vl * Mv * Dv * Fv),
+        "gemm_proj": ("mfma", 2.0 * (vl * Mv * Fv * Dv + tl * Mt * Ft * Dt)),
+        "gemm_fc_text": ("mfma", 2.0 * tl * Mt * Dt * Ft),
+    }
 
 
 def host_cores() -> int:
@@ -155,10 +178,20 @@ def main():
         e0.record(); step(); e1.record()
         torch.cuda.synchronize()
         breakdown = {"step_ms": round(e0.elapsed_time(e1), 3)}
+        work = class_work(cfg, b)
         for name, cid in PROF_CLASSES.items():
             t_, c_ = C.c_double(0), C.c_int(0)
             _lib.check(lib.ov_profile_read(cid, C.byref(t_), C.byref(c_), None), "prof read")
-            breakdown[name] = {"ms": round(t_.value, 3), "launches": c_.value}
+            ent = {"ms": round(t_.value, 3), "launches": c_.value}
+            if t_.value > 0:
+                bound, amount = work[name]
+                if bound == "mfma":
+                    ent.update(bound="mfma", achieved=round(amount / (t_.value * 1e-3) / 1e12, 1), unit="TFLOP/s",
+                               frac=round(amount / (t_.value * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4))
+                else:
+                    ent.update(bound="hbm", achieved=round(amount / (t_.value * 1e-3) / 1e9, 1), unit="GB/s",
+                               frac=round(amount / (t_.value * 1e-3) / 1e9 / PEAK_HBM_GBS, 4))
+            breakdown[name] = ent
         _lib.check(lib.ov_profile_enable(0, 0), "prof off")
 
     if rank == 0:
@@ -176,7 +209,9 @@ def main():
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tp):
             try:
-                traffic = json.load(open(tp)).get("gemm_fc_bytes_per_launch")
+                tj = json.load(open(tp))
+                if tj.get("model", "vit-large-patch14-224") == a.model and tj.get("batch", 256) == b:
+                    traffic = tj.get("gemm_fc_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {

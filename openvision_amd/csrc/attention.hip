@@ -501,6 +501,197 @@ __global__ __launch_bounds__(DEEP ? 512 : 640, DEEP ? 2 : 3) void attn_fwd_hd64_
 }
 
 // =====================================================================================================
+// Streaming variant for long sequences (padded L > 320; S/8@384: 2305 tokens).  One workgroup = 8 waves = 256 queries of
+// one (batch, head); K/V stream through a ring of four 16-KiB LDS slots in 64-key chunks (K image [64][128 B] +
+// V image [2 d-halves][64][64 B], same swizzles as above), LDS-DMA'd three chunks ahead.  Per chunk: a counted
+// vmcnt (the two younger chunks stay in flight), ONE raw barrier (the chunk has landed for everybody and everybody has
+// left the slot about to be refilled), the DMA of chunk c+3, then the two-key-tile step of the persistent kernel.
+// <= 128 VGPRs: two workgroups (2 x 64 KiB LDS) = 4 waves per SIMD share a CU, so one wave's softmax VALU work runs
+// under another's MFMAs.  Workgroup ids are dealt to XCDs so that the q-blocks of a head share that XCD's L2.
+struct AttnSArgs {
+    const ov_bf16* qkv; int64_t ldq;
+    ov_bf16* out; int64_t ldo;
+    int L, H, nqt, nqb, nheads, nchunks;
+    float scale_log2;
+};
+
+__global__ __launch_bounds__(512, 4) void attn_fwd_hd64_stream(const AttnSArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h2 = lane >> 5;
+    const int L = a.L;
+    // XCD-aware work map: workgroup id -> (head, q-block); the q-blocks of a head run back to back on one XCD
+    const int wid = blockIdx.x;
+    const int xcd = wid & 7, slot_id = wid >> 3;
+    const int bh = (slot_id / a.nqb) * 8 + xcd, qb = slot_id % a.nqb;
+    if (bh >= a.nheads) return;
+    const int b = bh / a.H, h = bh - b * a.H;
+    const int HD = a.H * 64;
+    const ov_bf16* base = a.qkv + (int64_t)b * L * a.ldq + h * 64;
+    const int qt = qb * 8 + wave;
+    const bool active = qt < a.nqt;
+    int qrow = qt * 32 + r;
+    qrow = qrow < L ? qrow : L - 1;
+
+    // ---- staging: thread tid moves one 16-B piece of K and one of V per chunk (32-bit byte offsets from `base`) ----
+    // K piece: key tid>>3, source d-chunk (tid&7) ^ ((key>>1)&7) (swizzle on the source side); V piece: d-half tid>>8, key
+    // (tid&255)>>2, d-chunk within the half tid&3.
+    char* const sdst = smem + wave * 1024;
+    const int nc = a.nchunks;
+    const char* const bbase = (const char*)base;
+    unsigned kofs = (unsigned)(((tid >> 3) * a.ldq + HD + (((tid & 7) ^ ((tid >> 4) & 7)) * 8)) * 2);
+    unsigned vofs = (unsigned)(((((tid & 255) >> 2)) * a.ldq + 2 * HD + ((tid >> 8) * 4 + (tid & 3)) * 8) * 2);
+    const unsigned cstep = (unsigned)(64 * a.ldq * 2);
+    auto stage = [&](int c) {                                     // chunks are staged in order 0, 1, 2, ...
+        char* dst = sdst + (c & 3) * 16384;
+        unsigned ko = kofs, vo = vofs;
+        if (c == nc - 1) {                                        // last chunk: rows past the sequence re-read row L-1 (finite; masked)
+            const int t = threadIdx.x;
+            const int over_k = c * 64 + (t >> 3) - (L - 1), over_v = c * 64 + ((t & 255) >> 2) - (L - 1);
+            if (over_k > 0) ko -= (unsigned)(over_k * a.ldq * 2);
+            if (over_v > 0) vo -= (unsigned)(over_v * a.ldq * 2);
+        }
+        __builtin_amdgcn_global_load_lds((gptr_t)(bbase + ko), (lptr_t)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(bbase + vo), (lptr_t)(dst + 8192), 16, 0, 0);
+        kofs += cstep;
+        vofs += cstep;
+    };
+    u32x4_t qn[4];
+    {
+        const ov_bf16* qp = base + (int64_t)qrow * a.ldq + 8 * h2;
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(qn[st]) : "v"(qp + 16 * st) : "memory");
+    }
+    stage(0);
+    if (nc > 1) stage(1);
+    if (nc > 2) stage(2);
+    // the Q rows are the oldest operations: complete once at most the (up to) 6 DMA pieces are outstanding
+    asm volatile("s_waitcnt vmcnt(6)" : "+v"(qn[0]), "+v"(qn[1]), "+v"(qn[2]), "+v"(qn[3]) :: "memory");
+    bf16x8_t qf[4];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) qf[st] = __builtin_bit_cast(bf16x8_t, qn[st]);
+
+    const int k_lane = r * 128;
+    const int k_sw = (r >> 1) & 7;
+    // fragment st of a key row sits at chunk (2 st + h2) ^ k_sw = (h2 ^ k_sw) ^ 2 st: one base, st by XOR (bits 5-6)
+    const int kbase = k_lane + ((h2 ^ k_sw) << 4);
+    const int vi = lane & 15, vg = (lane >> 4) & 1;
+    const int v_lane0 = 8192 + (4 * h2 + (vi >> 2)) * 64 + (16 * vg + 4 * (vi & 3)) * 2;    // d half 0 (half 1 = + 4096)
+    const unsigned smem_u = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)smem;
+
+    float m = -INFINITY, lsum = 0.f;
+    f32x16_t o0, o1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
+    auto tile_max = [&](const f32x16_t& sc) {
+        float mx = max3_asm(max3_asm(sc[0], sc[1], sc[2]), max3_asm(sc[3], sc[4], sc[5]), max3_asm(sc[6], sc[7], sc[8]));
+        return max3_asm(mx, max3_asm(sc[9], sc[10], sc[11]), max3_asm(max3_asm(sc[12], sc[13], sc[14]), sc[15], sc[15]));
+    };
+    auto pack_p = [&](const f32x16_t& sc, int st) {
+        const u32x4_t w = {pack_bf16x2(sc[8 * st + 0], sc[8 * st + 1]), pack_bf16x2(sc[8 * st + 2], sc[8 * st + 3]),
+                           pack_bf16x2(sc[8 * st + 4], sc[8 * st + 5]), pack_bf16x2(sc[8 * st + 6], sc[8 * st + 7])};
+        return __builtin_bit_cast(bf16x8_t, w);
+    };
+
+    for (int c = 0; c < nc; ++c) {
+        if (c + 2 < nc) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (c + 1 < nc) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        if (c + 3 < nc) stage(c + 3);
+        if (!active) continue;                                    // idle waves of the last q-block still stage and synchronise
+        const char* ks = smem + (c & 3) * 16384;
+        const unsigned va0 = smem_u + (c & 3) * 16384 + v_lane0, va1 = va0 + 4096;
+        // the second tile's K fragments are fetched behind the first tile's MFMAs (register room: 128 VGPRs)
+        bf16x8_t kfa[4], kfb[4];
+#pragma unroll
+        for (int st = 0; st < 4; ++st) kfa[st] = *(const bf16x8_t*)(ks + (kbase ^ (st << 5)));
+        f32x16_t sa, sb;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { sa[i] = 0.f; sb[i] = 0.f; }
+#pragma unroll
+        for (int st = 0; st < 4; ++st) sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfa[st], qf[st], sa, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int st = 0; st < 4; ++st) kfb[st] = *(const bf16x8_t*)(ks + 4096 + (kbase ^ (st << 5)));
+#pragma unroll
+        for (int st = 0; st < 4; ++st) sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfb[st], qf[st], sb, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        u32x2_t vt[8], vu[8];
+        vt[0] = tr_read_off<0>(va0);    vt[1] = tr_read_off<512>(va0);
+        vt[2] = tr_read_off<0>(va1);    vt[3] = tr_read_off<512>(va1);
+        vt[4] = tr_read_off<1024>(va0); vt[5] = tr_read_off<1536>(va0);
+        vt[6] = tr_read_off<1024>(va1); vt[7] = tr_read_off<1536>(va1);
+        if (c * 64 + 64 > L) {                                    // last chunk: keys past the sequence score -inf (P = 0)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int key = c * 64 + (i & 3) + 8 * (i >> 2) + 4 * h2;
+                if (key >= L) sa[i] = -INFINITY;
+                if (key + 32 >= L) sb[i] = -INFINITY;
+            }
+        }
+        float mx = fmaxf(tile_max(sa), tile_max(sb));
+        {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])) * a.scale_log2;
+        }
+        if (!__all(mx - m <= 8.0f)) {
+            const float mn = fmaxf(m, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m - mn);
+            m = mn;
+            lsum *= alpha;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+        }
+        const float nm = -m;
+        f32x2_t ps = {0.f, 0.f};
+        exp_rows(sa, a.scale_log2, nm, ps);
+        const bf16x8_t pa0 = pack_p(sa, 0), pa1 = pack_p(sa, 1);     // packed at once: the fp32 tile's registers retire early
+        exp_rows(sb, a.scale_log2, nm, ps);
+        const bf16x8_t pb0 = pack_p(sb, 0), pb1 = pack_p(sb, 1);
+        lsum += ps[0] + ps[1];
+        tr_wait(vt);
+        __builtin_amdgcn_sched_barrier(0);
+        vu[0] = tr_read_off<2048>(va0); vu[1] = tr_read_off<2560>(va0);
+        vu[2] = tr_read_off<2048>(va1); vu[3] = tr_read_off<2560>(va1);
+        vu[4] = tr_read_off<3072>(va0); vu[5] = tr_read_off<3584>(va0);
+        vu[6] = tr_read_off<3072>(va1); vu[7] = tr_read_off<3584>(va1);
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join(vt[0], vt[1]), pa0, o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join(vt[2], vt[3]), pa0, o1, 0, 0, 0);
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join(vt[4], vt[5]), pa1, o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join(vt[6], vt[7]), pa1, o1, 0, 0, 0);
+        tr_wait(vu);
+        __builtin_amdgcn_sched_barrier(0);
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join(vu[0], vu[1]), pb0, o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join(vu[2], vu[3]), pb0, o1, 0, 0, 0);
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join(vu[4], vu[5]), pb1, o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join(vu[6], vu[7]), pb1, o1, 0, 0, 0);
+    }
+    if (!active) return;
+    float l;
+    {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lsum), __float_as_uint(lsum), false, false);
+        l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
+    const float inv = 1.0f / l;
+    if (qt * 32 + r < L) {
+        ov_bf16* op = a.out + ((int64_t)b * L + qrow) * a.ldo + h * 64 + 4 * h2;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const u32x2_t w0 = {pack_bf16x2(o0[4 * gq] * inv, o0[4 * gq + 1] * inv),
+                                pack_bf16x2(o0[4 * gq + 2] * inv, o0[4 * gq + 3] * inv)};
+            const u32x2_t w1 = {pack_bf16x2(o1[4 * gq] * inv, o1[4 * gq + 1] * inv),
+                                pack_bf16x2(o1[4 * gq + 2] * inv, o1[4 * gq + 3] * inv)};
+            *(u32x2_t*)(op + 8 * gq) = w0;
+            *(u32x2_t*)(op + 32 + 8 * gq) = w1;
+        }
+    }
+}
+
+// =====================================================================================================
 // Generic head_dim kernel (head_dim 72 = So400m, 80 = H/14; any multiple of 8 up to 96): same S^T / P^T / O^T scheme with
 // the head padded to 96 in LDS (zero columns), 256-key chunks staged through registers, one key tile per step.  A plain,
 // correctness-first variant: these model sizes are not on the benchmark configuration.
@@ -708,6 +899,24 @@ extern "C" int ov_attention(const ov_bf16* qkv, int64_t ld_qkv, ov_bf16* out, in
             hipLaunchKernelGGL(attn_fwd_hd64_persist<true>, dim3((unsigned)grid), dim3(a.nqt * 64), smem, (hipStream_t)stream, p);
         else
             hipLaunchKernelGGL(attn_fwd_hd64_persist<false>, dim3((unsigned)grid), dim3(a.nqt * 64), smem, (hipStream_t)stream, p);
+        OV_LAUNCH_CHECK();
+        return OV_OK;
+    }
+    if (lp > 320 && !force_v1) {
+        AttnSArgs sa;
+        sa.qkv = qkv; sa.ldq = ld_qkv; sa.out = out; sa.ldo = ld_out;
+        sa.L = L; sa.H = H; sa.nqt = a.nqt; sa.nqb = (a.nqt + 7) / 8; sa.nheads = B * H; sa.nchunks = (L + 63) / 64;
+        sa.scale_log2 = a.scale_log2;
+        static bool attr4 = false;
+        if (!attr4) {
+            hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_hd64_stream, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return OV_ERR_HIP - (int)e;
+            attr4 = true;
+        }
+        const int64_t heads8 = ((int64_t)sa.nheads + 7) / 8 * 8;             // whole rounds of 8 XCDs; surplus ids exit at once
+        const int64_t nwg = heads8 * sa.nqb;
+        if (nwg > 0x7fffffffLL) return OV_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(attn_fwd_hd64_stream, dim3((unsigned)nwg), dim3(512), 4 * 16384, (hipStream_t)stream, sa);
         OV_LAUNCH_CHECK();
         return OV_OK;
     }

@@ -100,7 +100,9 @@ def test_gemm_patch_embed_row_maps():
     assert float(got[:, 0].abs().max()) == 0.0           # cls rows untouched
 
 
-@pytest.mark.parametrize("B,L,H_", [(2, 257, 16), (3, 101, 3), (2, 80, 12), (1, 32, 1), (1, 577, 2), (1, 2305, 2)])
+@pytest.mark.parametrize("B,L,H_", [(2, 257, 16), (3, 101, 3), (2, 80, 12), (1, 32, 1), (1, 577, 2), (1, 2305, 2),
+                                    # streaming kernel (padded L > 320): head counts off the XCD round, chunk tails of 1 / 33 / 64 keys
+                                    (3, 321, 3), (1, 384, 2), (1, 449, 1), (1, 481, 5), (1, 2304, 1)])
 def test_attention(B, L, H_):
     D = H_ * 64
     qkv = rnd(B * L, 3 * D, seed=20).to(torch.bfloat16)
@@ -125,11 +127,12 @@ def test_attention_generic_head_dim(B, L, H_, hd):
     np.testing.assert_allclose(o.numpy(), ref.numpy(), rtol=2e-2, atol=1.5e-2)
 
 
-def test_attention_online_softmax_rescale_branch():
-    """Force the running max to jump late (a spiked key in the LAST tile) — cdna guide rule 26."""
-    B, L, H_ = 1, 257, 1
+@pytest.mark.parametrize("L,spike", [(257, 250), (705, 700)])
+def test_attention_online_softmax_rescale_branch(L, spike):
+    """Force the running max to jump late (a spiked key in the LAST tile) — cdna guide rule 26.  L = 705: streaming kernel."""
+    B, H_ = 1, 1
     qkv = rnd(L, 192, seed=21).to(torch.bfloat16)
-    qkv[250, 64:128] = qkv[3, 0:64] * 6.0            # key 250 aligned with query 3 -> huge logit in the last tile
+    qkv[spike, 64:128] = qkv[3, 0:64] * 6.0          # that key aligned with query 3 -> huge logit in the last tile
     o = H.attention(qkv.to(DEV), B, L, H_).float().cpu()
     q, k, v = qkv.float().split(64, dim=-1)
     ref = torch.softmax(q * 0.125 @ k.T, dim=-1) @ v

@@ -23,7 +23,7 @@ for name, (N, K, epi) in cases.items():
     print(f"{name}: avg of 20 launches {e0.elapsed_time(e1) * 50:.1f} us = {2 * M * N * K / (e0.elapsed_time(e1) / 20 * 1e-3) / 1e12:.0f} TFLOP/s")
     if os.environ.get("STAMPS", "1") == "0":
         continue
-    slots = 20
+    slots = int(os.environ.get('SLOTS', '20'))
     SW = int(os.environ.get('STAMP_W', '8'))
     buf = torch.zeros(256 * slots * SW, dtype=torch.int64, device="cuda")
     lib.ov_debug_gemm_stamps(_lib.ptr(buf), slots)
