@@ -34,6 +34,7 @@ struct GemmArgs {
     const float* rowstats;          // LN fold: {mean, rstd} per row of A
     unsigned long long* stamps;     // diagnostics only (ov_debug_gemm_stamps): [block][tile slot][4] s_memtime values
     int stamp_slots;
+    int ngroup;                     // persistent kernel: n-tiles per group of the XCD tile walk (== tiles_n: plain n-fastest walk)
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -492,12 +493,26 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist(const GemmArgs 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     // ---- static persistent schedule: XCD x owns a contiguous run of tiles (n fastest), its workgroups stride it ----
+    // Plain walk (ngroup == tiles_n): the linear n-fastest tile list is cut into 8 contiguous runs.  Grouped walk (wide N):
+    // XCD x owns whole row panels [p0, p0 + pc) and walks them n-group by n-group -- (group, panel, n within group) -- so
+    // the W slice of a group (ngroup x 256 rows x K) stays in that XCD's 4 MiB L2 while the A panels stream past it;
+    // the plain walk re-fetches all of W from the Infinity Cache every round (8 MB > L2 at N = 4096, K = 1024).
     const int nwg = g.tiles_m * g.tiles_n;
     const int G = gridDim.x, bid = blockIdx.x;
     const int xcd = bid & 7, li = bid >> 3;
-    const int q8 = nwg >> 3, r8 = nwg & 7;
-    const int xstart = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
-    const int xcnt = q8 + (xcd < r8 ? 1 : 0);
+    const bool grouped = g.ngroup < g.tiles_n;
+    int xstart, xcnt, p0 = 0, pc = 1;
+    if (grouped) {
+        const int pq = g.tiles_m >> 3, pr = g.tiles_m & 7;
+        p0 = xcd * pq + (xcd < pr ? xcd : pr);
+        pc = pq + (xcd < pr ? 1 : 0);
+        xstart = 0;
+        xcnt = pc * g.tiles_n;
+    } else {
+        const int q8 = nwg >> 3, r8 = nwg & 7;
+        xstart = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+        xcnt = q8 + (xcd < r8 ? 1 : 0);
+    }
     const int nper = (G - xcd + 7) >> 3;
     int tcur = li;
     if (tcur >= xcnt) return;
@@ -508,8 +523,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist(const GemmArgs 
     int64_t m0, nm0 = 0;
     int n0, nn0 = 0;
     auto set_tile = [&](int trel, TileSrc& ts, int64_t& mm, int& nn) {
-        const int wg = xstart + trel;
-        const int tm = wg / g.tiles_n, tn = wg - tm * g.tiles_n;
+        int tm, tn;
+        if (grouped) {
+            const int per = pc * g.ngroup;
+            const int ng = trel / per, rem = trel - ng * per;
+            const int pm = rem / g.ngroup;
+            tm = p0 + pm;
+            tn = ng * g.ngroup + (rem - pm * g.ngroup);
+        } else {
+            const int wg = xstart + trel;
+            tm = wg / g.tiles_n;
+            tn = wg - tm * g.tiles_n;
+        }
         mm = (int64_t)tm * BM;
         nn = tn * BN;
         int64_t ar0 = mm + srow, ar1 = mm + 128 + srow;
@@ -719,6 +744,23 @@ int gemm_variant() {       // 0 = persistent ping-pong (default), 1 = v1 two-sta
     return v;
 }
 
+// n-tiles per group of the persistent walk: groups of 4 once W no longer fits an XCD's L2 next to the streaming A panels
+// (OVHIP_GEMM_NGROUP: 0 = never group, n = force groups of n where tiles_n is a multiple)
+int gemm_ngroup(int tiles_m, int tiles_n, int K) {
+    static int force = -2;
+    if (force == -2) {
+        const char* e = getenv("OVHIP_GEMM_NGROUP");
+        force = e ? atoi(e) : -1;
+    }
+    int gsz = 4;
+    if (force == 0) return tiles_n;
+    if (force > 0) gsz = force;
+    const int64_t wbytes = (int64_t)tiles_n * BN * K * 2;
+    if (force < 0 && wbytes <= (3 << 20)) return tiles_n;
+    if (tiles_n <= gsz || tiles_n % gsz || tiles_m < 16) return tiles_n;
+    return gsz;
+}
+
 template <int EPI>
 int launch(GemmArgs a, hipStream_t st) {
     int var = gemm_variant();
@@ -760,7 +802,7 @@ extern "C" int ov_gemm(const ov_bf16* A, int64_t lda, const ov_bf16* W, int64_t 
     const int64_t tiles_n = (N + BN - 1) / BN;
     if (tiles_m * tiles_n > 0x7fffffffLL || M > 0x7fff0000LL) return OV_ERR_UNSUPPORTED;    // 32-bit row indices in the kernels
     GemmArgs a{A, W, bias, C, R, lda, ldw, ldc, ldr, M, N, K, (int)tiles_m, (int)tiles_n,
-               out_group, resid_mod, resid_off, g_colsum, g_rowstats, g_stamps, g_stamp_slots};
+               out_group, resid_mod, resid_off, g_colsum, g_rowstats, g_stamps, g_stamp_slots, gemm_ngroup((int)tiles_m, (int)tiles_n, K)};
     hipStream_t st = (hipStream_t)stream;
     switch (epilogue) {
         case OV_EPI_BIAS: return launch<OV_EPI_BIAS>(a, st);
