@@ -17,6 +17,7 @@
  *   ov_l2norm           F.normalize(x, dim=-1)                                model.py:267,284
  *   ov_logits           CLIP.get_logits (scale * img @ txt^T)                 model.py:286-293
  *   ov_clip_loss        ClipLoss.get_logits + cross_entropy both ways         loss.py:102-131
+ *   ov_preprocess_image transforms.Resize -> ToTensor -> Normalize (Pillow-exact)  ov-zero-shot-test.py:72-77, transform.py:355-392
  *   ov_class_mean_normalize / ov_topk   zero-shot classifier weights, argmax / recall@k ranking   zero_shot_classifier.py:54-57,
  *                       src/evaluators/proj/image_text/{discriminative_classifier.py:305-323, image_text_retrieval.py:24-87}
  *   ov_tower_*          Transformer.forward (the resblock loop)               transformer.py:355-366, 254-265
@@ -135,6 +136,18 @@ int ov_l2norm(const void* x, int x_dtype, int64_t ldx, float* y, int64_t ldy, in
 /* out[i, j] = scale * <X[i,:], Y[j,:]>  fp32 in/out (CLIP.get_logits: model.py:286-293).  E % 8 == 0. */
 int ov_logits(const float* X, const float* Y, float* out, int64_t ldo, int n1, int n2, int E, float scale,
               ov_stream_t stream);
+
+/* ---- image front-end: Resize [+ CenterCrop] -> ToTensor -> Normalize on the device ----------------
+ * Bit-exact counterpart of PIL.Image.resize (what torchvision's Resize runs on a PIL image: reference ov-zero-shot-test.py:72-77,
+ * open_clip/transform.py:355-392) followed by x / 255 and (x - mean) / std in IEEE fp32.
+ * src: uint8 RGB [H, W, 3] (device).  bounds_x [Wr][2] = {first source column, tap count}, coef_x [Wr][ksize_x] = Pillow's 22-bit
+ * fixed-point taps (device int32), same for y over Hr output rows; row0/nrows = the source rows the vertical pass reads
+ * (Pillow's ybox); tmp: uint8 [nrows, Wr, 3] scratch (device).  The [out_h, out_w] window at (crop_x, crop_y) of the resized
+ * [Hr, Wr] image is written as CHW [3, out_h, out_w] in out_dtype (OV_F32 / OV_BF16).  mean / stdv: HOST float[3]. */
+int ov_preprocess_image(const unsigned char* src, int H, int W, const int* bounds_x, const int* coef_x, int ksize_x, int Wr,
+                        const int* bounds_y, const int* coef_y, int ksize_y, int Hr, int row0, int nrows, unsigned char* tmp,
+                        int crop_x, int crop_y, int out_h, int out_w, const float* mean, const float* stdv, void* out,
+                        int out_dtype, ov_stream_t stream);
 
 /* ---- consumers of encode + logits: zero-shot classifier weights and ranking ------------
  * out[c,:] = normalize(mean_t emb[c*T + t, :])   (open_clip/zero_shot_classifier.py:54-57).  fp32 in/out. */

@@ -63,6 +63,8 @@ SIGNATURES = {
     "ov_convert": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_int64, c_int, c_void_p]),
     "ov_l2norm": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "ov_logits": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_float, c_void_p]),
+    "ov_preprocess_image": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
+                                    c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "ov_class_mean_normalize": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ov_topk": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ov_clip_loss_workspace_bytes": (c_size_t, [c_int, c_int]),

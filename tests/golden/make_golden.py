@@ -14,6 +14,7 @@ are written; weights are NOT stored — they are rebuilt from ``openvision_amd.s
 Files written (np.savez_compressed):
   ops.npz                 LayerNorm / GELU(erf,tanh) / ResidualAttentionBlock of the reference on small inputs
   tiny16_160.npz          Ti/16@160 + text-Ti: tokens after block 0 / last block, features, logits, loss
+  preprocess.npz          Pillow resize / ToTensor / Normalize outputs on the testcat PNGs and three synthetic images
   tiny16_160_testcat.npz  the 5 testcat PNGs (resized to 160, normalised) x 9 caption rows: cosine/probs/argsort
   large14_224.npz         L/14@224 + text-L, B=2: features (fp32 and the reference's bf16 mode), token slices
   small8_384.npz          S/8@384, B=1 (2305 tokens): features, token slices
@@ -209,6 +210,46 @@ def _loss_worker(rank, ws, store, ref_root, feats, q):
     dist.destroy_process_group()
 
 
+def gen_preprocess(ref_root, out):
+    """Pillow (the library torchvision's Resize runs on a PIL image) as the reference of the image transform of
+    ov-zero-shot-test.py:72-77 (Resize((S, S)) in the file's own mode, THEN convert("RGB"), ToTensor, Normalize) and of
+    open_clip/transform.py:355-392 ('shortest' + CenterCrop, bicubic).  Inputs: the 5 testcat PNGs (RGB view; their alpha is
+    255 everywhere, so resizing in RGBA and dropping alpha equals resizing the RGB view) and three synthetic images."""
+    from PIL import Image
+    pp = ovcfg.DEFAULT_PREPROCESS
+    mean, std = np.asarray(pp["mean"], np.float32), np.asarray(pp["std"], np.float32)
+    d = {}
+    names = sorted(n for n in os.listdir(os.path.join(ref_root, "testcat")) if n.lower().endswith(".png"))
+    for i, n in enumerate(names):
+        im = Image.open(os.path.join(ref_root, "testcat", n))
+        if im.mode == "RGBA":
+            assert np.asarray(im)[..., 3].min() == 255
+        d[f"cat{i}_in"] = np.asarray(im.convert("RGB"))
+        r = im.resize((160, 160), Image.BILINEAR).convert("RGB")            # script order: resize, then convert
+        d[f"cat{i}_u8"] = np.asarray(r)
+        if i < 2:          # the float stage is elementwise: two images pin it, the uint8 stage is pinned on all five
+            x = torch.from_numpy(np.asarray(r).copy()).permute(2, 0, 1).float().div(255)      # ToTensor
+            d[f"cat{i}_out"] = ((x - torch.tensor(mean)[:, None, None]) / torch.tensor(std)[:, None, None]).numpy()   # Normalize
+    g = np.random.default_rng(5)
+    synth_imgs = {"noise": g.integers(0, 256, (97, 131, 3), dtype=np.uint8),
+                  "grad": (np.add.outer(np.arange(300), np.arange(211))[..., None] * np.array([1, 2, 3]) % 256).astype(np.uint8),
+                  "up": g.integers(0, 256, (40, 56, 3), dtype=np.uint8)}
+    for k, img in synth_imgs.items():
+        d[f"{k}_in"] = img
+        h, w = img.shape[:2]
+        # transform.py 'shortest': Resize(224, BICUBIC) on the short edge, CenterCrop(224)
+        if w <= h:
+            wr, hr = 224, int(224 * h / w)
+        else:
+            hr, wr = 224, int(224 * w / h)
+        r = Image.fromarray(img).resize((wr, hr), Image.BICUBIC)
+        top, left = int(round((hr - 224) / 2.0)), int(round((wr - 224) / 2.0))
+        r = np.asarray(r)[top:top + 224, left:left + 224]
+        d[f"{k}_u8_shortest_bicubic"] = r
+        d[f"{k}_u8_squash_bilinear"] = np.asarray(Image.fromarray(img).resize((160, 160), Image.BILINEAR))
+    np.savez_compressed(out, names=np.array(names), **d)
+
+
 def gen_cliploss(lossmod, ref_root, out):
     import torch.multiprocessing as mp
     g = torch.Generator().manual_seed(99)
@@ -246,6 +287,7 @@ def main():
         "large": lambda: gen_large(m, lossmod, os.path.join(HERE, "large14_224.npz")),
         "small": lambda: gen_small(m, os.path.join(HERE, "small8_384.npz")),
         "cliploss": lambda: gen_cliploss(lossmod, a.ref, os.path.join(HERE, "cliploss_ws.npz")),
+        "preprocess": lambda: gen_preprocess(a.ref, os.path.join(HERE, "preprocess.npz")),
     }
     for k, fn in jobs.items():
         if a.only and k not in a.only.split(","):

@@ -230,6 +230,38 @@ def test_zero_shot_and_retrieval_evaluators(tiny):
     assert ev.topk(x, 2, largest=False)[1].tolist() == [[0, 3], [0, 1]]
 
 
+def test_device_preprocess_bit_exact():
+    """SURVEY.md §8f row 2 (image half): HIP resize + ToTensor + Normalize against Pillow's committed outputs (uint8 stage via the
+    float output: x / 255 and (x - mean) / std are exact IEEE ops) and against the numpy oracle on odd geometries."""
+    from oracle import preprocess_ref as P
+    from openvision_amd import preprocess as pp
+    from openvision_amd.config import DEFAULT_PREPROCESS as PPC
+    g = golden("preprocess.npz")
+    mean, std = PPC["mean"], PPC["std"]
+    cats = [g[f"cat{i}_in"] for i in range(5)]
+    out = pp.preprocess(cats, 160, mean, std, "squash", "bilinear", device=DEV).cpu().numpy()
+    for i in range(2):
+        assert np.array_equal(out[i], g[f"cat{i}_out"])                               # the script's transform, bit for bit
+    for i in range(5):
+        u8 = g[f"cat{i}_u8"].astype(np.float32) / np.float32(255.0)
+        ref = ((u8 - np.asarray(mean, np.float32)) / np.asarray(std, np.float32)).transpose(2, 0, 1)
+        assert np.array_equal(out[i], ref)
+    imgs = [g["noise_in"], g["grad_in"], g["up_in"]]
+    got = pp.preprocess(imgs, 224, mean, std, "shortest", "bicubic", device=DEV).cpu().numpy()
+    for k, o in zip(("noise", "grad", "up"), got):
+        ref = ((g[f"{k}_u8_shortest_bicubic"].astype(np.float32) / np.float32(255.0) - np.asarray(mean, np.float32))
+               / np.asarray(std, np.float32)).transpose(2, 0, 1)
+        assert np.array_equal(o, ref)
+    rng = np.random.default_rng(9)
+    odd = [rng.integers(0, 256, s, dtype=np.uint8) for s in [(5, 7, 3), (333, 77, 3), (160, 160, 3), (1, 1, 3), (640, 481, 3)]]
+    for mode, interp, size in (("squash", "bicubic", 160), ("shortest", "bilinear", 64)):
+        got = pp.preprocess(odd, size, mean, std, mode, interp, device=DEV).cpu().numpy()
+        for im, o in zip(odd, got):
+            assert np.array_equal(o, P.transform(im, size, mean, std, mode, interp))
+    b16 = pp.preprocess(cats[:1], 160, mean, std, dtype=torch.bfloat16, device=DEV)
+    assert torch.equal(b16.float().cpu(), torch.from_numpy(out[:1]).to(torch.bfloat16).float())
+
+
 def test_checkpoint_dir_to_device(tiny, tmp_path):
     from openvision_amd import checkpoint as ck
     cfg = preset("vit-tiny-patch16-160")
