@@ -558,21 +558,18 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_hd64_stream(const AttnSArgs a
         kofs += cstep;
         vofs += cstep;
     };
-    u32x4_t qn[4];
+    // Q rows: ordinary loads, waited for by the compiler (once per workgroup).  Not the inline-asm form of the persistent
+    // kernel: an asm load's destination can be spilled or copied right behind the asm statement, before the data has landed
+    // (seen with a 128-VGPR ping-pong variant of this kernel: the late write then hit live address registers).
+    bf16x8_t qf[4];
     {
         const ov_bf16* qp = base + (int64_t)qrow * a.ldq + 8 * h2;
 #pragma unroll
-        for (int st = 0; st < 4; ++st)
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(qn[st]) : "v"(qp + 16 * st) : "memory");
+        for (int st = 0; st < 4; ++st) qf[st] = *(const bf16x8_t*)(qp + 16 * st);
     }
     stage(0);
     if (nc > 1) stage(1);
     if (nc > 2) stage(2);
-    // the Q rows are the oldest operations: complete once at most the (up to) 6 DMA pieces are outstanding
-    asm volatile("s_waitcnt vmcnt(6)" : "+v"(qn[0]), "+v"(qn[1]), "+v"(qn[2]), "+v"(qn[3]) :: "memory");
-    bf16x8_t qf[4];
-#pragma unroll
-    for (int st = 0; st < 4; ++st) qf[st] = __builtin_bit_cast(bf16x8_t, qn[st]);
 
     const int k_lane = r * 128;
     const int k_sw = (r >> 1) & 7;

@@ -3,7 +3,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import hipops as H
-B, L, Hh = 256, int(os.environ.get("L", "257")), 16
+B, L, Hh = int(os.environ.get("B", "256")), int(os.environ.get("L", "257")), int(os.environ.get("H", "16"))
 qkv = torch.randn(B * L, 3 * Hh * 64, device="cuda").to(torch.bfloat16)
 for _ in range(3):
     H.attention(qkv, B, L, Hh)
@@ -13,4 +13,5 @@ e0.record()
 for _ in range(20):
     H.attention(qkv, B, L, Hh)
 e1.record(); torch.cuda.synchronize()
-print("mode", os.environ.get("OVHIP_ATTN_MODE", "0"), "ms/launch", e0.elapsed_time(e1) / 20)
+ms = e0.elapsed_time(e1) / 20
+print("mode", os.environ.get("OVHIP_ATTN_MODE", "0"), "B", B, "L", L, "H", Hh, "ms/launch", ms, "TFLOP/s", 4.0 * B * Hh * L * L * 64 / (ms * 1e-3) / 1e12)
