@@ -23,6 +23,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL; must be set before the HIP runtime starts
+
 import torch                      # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
