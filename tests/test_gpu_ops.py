@@ -102,7 +102,9 @@ def test_gemm_patch_embed_row_maps():
 
 @pytest.mark.parametrize("B,L,H_", [(2, 257, 16), (3, 101, 3), (2, 80, 12), (1, 32, 1), (1, 577, 2), (1, 2305, 2),
                                     # streaming kernel (padded L > 320): head counts off the XCD round, chunk tails of 1 / 33 / 64 keys
-                                    (3, 321, 3), (1, 384, 2), (1, 449, 1), (1, 481, 5), (1, 2304, 1)])
+                                    (3, 321, 3), (1, 384, 2), (1, 449, 1), (1, 481, 5), (1, 2304, 1),
+                                    # L = 32 k + 1: the lone query row is shared out over the k waves (XROW)
+                                    (2, 33, 1), (3, 65, 2), (1, 129, 5), (2, 225, 3), (300, 257, 16)])
 def test_attention(B, L, H_):
     D = H_ * 64
     qkv = rnd(B * L, 3 * D, seed=20).to(torch.bfloat16)
