@@ -17,6 +17,7 @@
  *   ov_l2norm           F.normalize(x, dim=-1)                                model.py:267,284
  *   ov_logits           CLIP.get_logits (scale * img @ txt^T)                 model.py:286-293
  *   ov_clip_loss        ClipLoss.get_logits + cross_entropy both ways         loss.py:102-131
+ *   ov_gemm_fp8         the same nn.Linear on fp8 e4m3 operands (config #5)           transformer.py:225,232-236
  *   ov_preprocess_image transforms.Resize -> ToTensor -> Normalize (Pillow-exact)  ov-zero-shot-test.py:72-77, transform.py:355-392
  *   ov_class_mean_normalize / ov_topk   zero-shot classifier weights, argmax / recall@k ranking   zero_shot_classifier.py:54-57,
  *                       src/evaluators/proj/image_text/{discriminative_classifier.py:305-323, image_text_retrieval.py:24-87}
@@ -136,6 +137,15 @@ int ov_l2norm(const void* x, int x_dtype, int64_t ldx, float* y, int64_t ldy, in
 /* out[i, j] = scale * <X[i,:], Y[j,:]>  fp32 in/out (CLIP.get_logits: model.py:286-293).  E % 8 == 0. */
 int ov_logits(const float* X, const float* Y, float* out, int64_t ldo, int n1, int n2, int E, float scale,
               ov_stream_t stream);
+
+/* ---- fp8 GEMM (BASELINE.json config #5: fp8 weights/activations on the CDNA4 fp8 MFMA) --------------------------------------
+ * C = epilogue(rowscale[m] * colscale[n] * (A . W^T) + bias):  A [M, K], W [N, K] OCP e4m3fn bytes (K contiguous, lda/ldw in
+ * bytes, % 16), rowscale [M] / colscale [N] fp32 dequantisation scales (per activation row / per weight row), bias fp32 or NULL,
+ * C (and R for OV_EPI_BIAS_RESIDUAL) bf16.  K % 128 == 0, K >= 384, N % 8 == 0.  Epilogues: OV_EPI_BIAS, OV_EPI_BIAS_GELU_ERF,
+ * OV_EPI_BIAS_RESIDUAL.  Accumulation in fp32 on v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales). */
+int ov_gemm_fp8(const unsigned char* A, int64_t lda, const unsigned char* W, int64_t ldw, const float* rowscale,
+                const float* colscale, const float* bias, ov_bf16* C, int64_t ldc, int64_t M, int N, int K, int epilogue,
+                const ov_bf16* R, int64_t ldr, ov_stream_t stream);
 
 /* ---- image front-end: Resize [+ CenterCrop] -> ToTensor -> Normalize on the device ----------------
  * Bit-exact counterpart of PIL.Image.resize (what torchvision's Resize runs on a PIL image: reference ov-zero-shot-test.py:72-77,

@@ -50,6 +50,8 @@ SIGNATURES = {
                              c_float, c_void_p]),
     "ov_gemm": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int,
                         c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    "ov_gemm_fp8": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int,
+                            c_int, c_void_p, c_int64, c_void_p]),
     "ov_gemm_ln": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int,
                            c_int, c_int, c_void_p]),
     "ov_rowstats": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_float, c_void_p]),

@@ -66,3 +66,22 @@ def gemm_ln(x, wg, cvec, colsum, stats, epi=0):
     check(lib.ov_gemm_ln(ptr(x), x.stride(0), ptr(wg), wg.stride(0), ptr(cvec), ptr(colsum), ptr(stats), ptr(out), out.stride(0),
                          m, n, k, epi, stream_ptr()))
     return out
+
+
+def quantize_rows_e4m3(x):
+    """Per-row absmax scaling to OCP e4m3fn (max 448): returns (uint8 view of the fp8 tensor, fp32 scales)."""
+    amax = x.float().abs().amax(dim=1).clamp_min(1e-12)
+    scale = amax / 448.0
+    q = (x.float() / scale[:, None]).to(torch.float8_e4m3fn)
+    return q.view(torch.uint8).contiguous(), scale.contiguous()
+
+
+def gemm_fp8(aq, wq, rowscale, colscale, bias=None, epi=0, resid=None):
+    lib = _lib.load()
+    m, k = aq.shape
+    n = wq.shape[0]
+    out = torch.empty(m, n, dtype=torch.bfloat16, device=aq.device)
+    check(lib.ov_gemm_fp8(ptr(aq), aq.stride(0), ptr(wq), wq.stride(0), ptr(rowscale), ptr(colscale),
+                          ptr(bias) if bias is not None else None, ptr(out), out.stride(0), m, n, k, epi,
+                          ptr(resid) if resid is not None else None, resid.stride(0) if resid is not None else 0, stream_ptr()))
+    return out

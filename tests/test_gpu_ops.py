@@ -169,3 +169,38 @@ def test_clip_loss_golden_reference_ranks():
             l, _ = H.clip_loss(img[r * b:(r + 1) * b].contiguous().to(DEV), txt[r * b:(r + 1) * b].contiguous().to(DEV),
                                img.to(DEV), txt.to(DEV), s, r * b)
             assert abs(float(l) - float(g[f"local_losses_ws{ws}"][r])) < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(256, 256, 384, 0), (300, 520, 512, 0), (771, 3072, 1024, 1), (2048, 1024, 4096, 3),
+                                       (65535, 1024, 1024, 0)])
+def test_gemm_fp8_matches_dequantised_fp32(M, N, K, epi):
+    """BASELINE.json config #5 building block: fp8 e4m3 operands on the MX-scaled MFMA (unit block scales), per-row / per-channel
+    dequantisation in the epilogue.  fp8 x fp8 products are exact in fp32, so the only differences from an fp32 matmul of the
+    dequantised operands are the accumulation order and the bf16 rounding of the output."""
+    a = rnd(M, K, seed=40) * (rnd(M, 1, seed=41).abs() * 3 + 0.2)
+    w = rnd(N, K, seed=42) / K ** 0.5
+    bias = rnd(N, seed=43)
+    aq, rs = H.quantize_rows_e4m3(a.to(DEV))
+    wq, cs = H.quantize_rows_e4m3(w.to(DEV))
+    res = rnd(M, N, seed=44).to(torch.bfloat16) if epi == 3 else None
+    out = H.gemm_fp8(aq, wq, rs, cs, bias.to(DEV), epi, res.to(DEV) if res is not None else None).float().cpu()
+    ad = (aq.view(torch.float8_e4m3fn).float() * rs[:, None]).cpu()
+    wd = (wq.view(torch.float8_e4m3fn).float() * cs[:, None]).cpu()
+    ref = ad.double() @ wd.double().T + bias.double()
+    if epi == 1:
+        ref = torch.nn.functional.gelu(ref)
+    if epi == 3:
+        ref = ref + res.double()
+    np.testing.assert_allclose(out.numpy(), ref.float().numpy(), rtol=1e-2, atol=2e-2)
+    # and the quantisation itself stays within e4m3 resolution (2^-4 relative) of the unquantised product at the GEMM level
+    full = a.double() @ w.double().T + bias.double()
+    if epi == 0:
+        rel = (ref - full).norm() / full.norm()
+        assert rel < 0.05, rel
+
+
+def test_gemm_fp8_rejects_unsupported():
+    aq = torch.zeros(256, 128, dtype=torch.uint8, device=DEV)
+    s1 = torch.ones(256, device=DEV)
+    with pytest.raises(Exception):
+        H.gemm_fp8(aq, aq, s1, s1)                # K = 128 < 384
