@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--model", default="vit-large-patch14-224")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--breakdown", action="store_true", help="extra untimed step timing every kernel class")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp8"], help="GEMM operand precision of the block stacks")
     return ap.parse_args()
 
 
@@ -133,6 +134,8 @@ def main():
     cfg = preset(a.model)
     sd = synth.make_state_dict(cfg, seed=0)
     model = create_model(cfg, device=dev, state_dict=sd)
+    if a.precision != "bf16":
+        model.set_precision(a.precision)
     loss_fn = ClipLoss(local_loss=True, rank=rank, world_size=world)
     b = a.batch
     S = cfg["vision_cfg"]["image_size"]
@@ -224,9 +227,9 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
+            "dtype": a.precision, "data": "synthetic",
             "config": {"workload": f"{a.model}: image tower + text tower (T={T}) + InfoNCE, per-GPU batch {b}, "
-                                   f"formula weights, bf16 MFMA / fp32 accumulate",
+                                   f"formula weights, {'bf16' if a.precision == 'bf16' else 'fp8 e4m3 (MX-scaled)'} MFMA / fp32 accumulate",
                        "global_batch": world * b, "parallelism": f"dp{world}",
                        "gflop_per_pair": round(flops["pair"] / 1e9, 2),
                        "model_tflops_per_gpu": round(flops["pair"] * b * a.steps / dt / 1e12, 1)},

@@ -147,6 +147,14 @@ int ov_gemm_fp8(const unsigned char* A, int64_t lda, const unsigned char* W, int
                 const float* colscale, const float* bias, ov_bf16* C, int64_t ldc, int64_t M, int N, int K, int epilogue,
                 const ov_bf16* R, int64_t ldr, ov_stream_t stream);
 
+/* Activation quantisation for ov_gemm_fp8: q[r,:] = e4m3(y[r,:] / s_r), s_r = max|y[r,:]| / 448, with y = x (ov_quant_rows_fp8) or
+ * y = LayerNorm(x) * gamma + beta in fp32 (ov_layernorm_quant_fp8; eps, biased variance as transformer.py:15-30).  x bf16
+ * [rows, D] (ldx), q bytes [rows, D] (ldq, % 8), rowscale [rows] fp32.  D % 8 == 0, D <= 8192. */
+int ov_quant_rows_fp8(const ov_bf16* x, int64_t ldx, unsigned char* q, int64_t ldq, float* rowscale, int64_t rows, int D,
+                      ov_stream_t stream);
+int ov_layernorm_quant_fp8(const ov_bf16* x, int64_t ldx, const float* gamma, const float* beta, unsigned char* q, int64_t ldq,
+                           float* rowscale, int64_t rows, int D, float eps, ov_stream_t stream);
+
 /* ---- image front-end: Resize [+ CenterCrop] -> ToTensor -> Normalize on the device ----------------
  * Bit-exact counterpart of PIL.Image.resize (what torchvision's Resize runs on a PIL image: reference ov-zero-shot-test.py:72-77,
  * open_clip/transform.py:355-392) followed by x / 255 and (x - mean) / std in IEEE fp32.
@@ -222,9 +230,22 @@ typedef struct {      /* one ResidualAttentionBlock; weights bf16 [out,in] row-m
     const float* fc_colsum;                        /* [mlp_pad] */
 } ov_block_weights;
 
+typedef struct {      /* optional fp8 (OCP e4m3) copies of a block's four weight matrices for the fp8 path (config #5): bytes
+                       * [out, in] row-major + one fp32 dequantisation scale per output row; qkv_b / fc_b are the module's own
+                       * biases (ov_block_weights holds the LN-folded ones), out/proj biases are taken from ov_block_weights */
+    const unsigned char* qkv_w8;  const float* qkv_s;  const float* qkv_b;     /* [3D, D], [3D], [3D]           */
+    const unsigned char* out_w8;  const float* out_s;                         /* [D, D], [D]                   */
+    const unsigned char* fc_w8;   const float* fc_s;   const float* fc_b;      /* [mlp_pad, D], [mlp_pad] x 2   */
+    const unsigned char* proj_w8; const float* proj_s;                        /* [D, mlp_pad], [D]             */
+} ov_block_fp8;
+
 ov_tower* ov_tower_create(const ov_tower_cfg* cfg);
 void      ov_tower_destroy(ov_tower* t);
 int       ov_tower_set_block(ov_tower* t, int layer, const ov_block_weights* w);
+/* Once EVERY layer has an fp8 copy (and until one is cleared with q == NULL) ov_tower_forward runs the fp8 path: LayerNorm fused
+ * with row quantisation, fp8 GEMMs (ov_gemm_fp8), bf16 attention, row re-quantisation in front of out_proj / c_proj.  Needs
+ * width and mlp_pad % 128 == 0 and >= 384.  ov_tower_workspace_bytes grows accordingly: query it after setting the copies. */
+int       ov_tower_set_block_fp8(ov_tower* t, int layer, const ov_block_fp8* q);
 size_t    ov_tower_workspace_bytes(const ov_tower* t, int B, int L);
 /* x[B*L, D] bf16 is updated in place through all `layers` blocks. */
 int       ov_tower_forward(const ov_tower* t, ov_bf16* x, int B, int L, void* workspace,

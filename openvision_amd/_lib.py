@@ -28,6 +28,10 @@ class BlockWeights(C.Structure):
                                         "fc_w", "fc_b", "proj_w", "proj_b", "qkv_colsum", "fc_colsum")]
 
 
+class BlockFp8(C.Structure):
+    _fields_ = [(n, c_void_p) for n in ("qkv_w8", "qkv_s", "qkv_b", "out_w8", "out_s", "fc_w8", "fc_s", "fc_b", "proj_w8", "proj_s")]
+
+
 class VisionHead(C.Structure):
     _fields_ = [("image_size", c_int), ("patch_size", c_int), ("kpad", c_int), ("pool_avg", c_int),
                 ("final_ln_after_pool", c_int), ("embed_dim", c_int), ("embed_pad", c_int),
@@ -52,6 +56,9 @@ SIGNATURES = {
                         c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "ov_gemm_fp8": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int,
                             c_int, c_void_p, c_int64, c_void_p]),
+    "ov_quant_rows_fp8": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p]),
+    "ov_layernorm_quant_fp8": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_float,
+                                       c_void_p]),
     "ov_gemm_ln": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int,
                            c_int, c_int, c_void_p]),
     "ov_rowstats": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_float, c_void_p]),
@@ -78,6 +85,7 @@ SIGNATURES = {
     "ov_tower_create": (c_void_p, [C.POINTER(TowerCfg)]),
     "ov_tower_destroy": (None, [c_void_p]),
     "ov_tower_set_block": (c_int, [c_void_p, c_int, C.POINTER(BlockWeights)]),
+    "ov_tower_set_block_fp8": (c_int, [c_void_p, c_int, c_void_p]),
     "ov_tower_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
     "ov_tower_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "ov_vision_workspace_bytes": (c_size_t, [c_void_p, C.POINTER(VisionHead), c_int]),

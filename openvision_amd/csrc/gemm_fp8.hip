@@ -122,6 +122,7 @@ __device__ __forceinline__ void epilogue_fp8(const Fp8Args& g, f32x4_t (&acc)[8]
                 v01 = __builtin_elementwise_fma(v01, f32x2_t{cq[j][0], cq[j][1]}, b01);
                 v23 = __builtin_elementwise_fma(v23, f32x2_t{cq[j][2], cq[j][3]}, b23);
                 if (EPI == OV_EPI_BIAS_GELU_ERF) gelu_erf_f2x2(v01, v23);
+                if (EPI == OV_EPI_BIAS_GELU_TANH) { v01 = gelu_tanh_f2(v01); v23 = gelu_tanh_f2(v23); }
                 const u32x2_t pk = {pack_bf16x2(v01[0], v01[1]), pack_bf16x2(v23[0], v23[1])};
                 *(u32x2_t*)(wr + (((j * 2 + (fq >> 1)) ^ wsw) << 4)) = pk;
             }
@@ -385,6 +386,7 @@ extern "C" int ov_gemm_fp8(const unsigned char* A, int64_t lda, const unsigned c
     switch (epilogue) {
         case OV_EPI_BIAS: return launch_fp8<OV_EPI_BIAS>(a, st);
         case OV_EPI_BIAS_GELU_ERF: return launch_fp8<OV_EPI_BIAS_GELU_ERF>(a, st);
+        case OV_EPI_BIAS_GELU_TANH: return launch_fp8<OV_EPI_BIAS_GELU_TANH>(a, st);
         case OV_EPI_BIAS_RESIDUAL: return launch_fp8<OV_EPI_BIAS_RESIDUAL>(a, st);
         default: return OV_ERR_UNSUPPORTED;
     }

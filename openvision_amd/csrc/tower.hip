@@ -20,6 +20,8 @@ struct ov_tower {
     ov_tower_cfg cfg;
     ov_block_weights* blocks;
     unsigned char* set;
+    ov_block_fp8* fp8;            // optional fp8 copies (config #5); the fp8 path runs when every layer has one
+    unsigned char* set8;
 };
 
 namespace {
@@ -164,7 +166,9 @@ extern "C" ov_tower* ov_tower_create(const ov_tower_cfg* cfg) {
     t->cfg = *cfg;
     t->blocks = new (std::nothrow) ov_block_weights[cfg->layers]();
     t->set = new (std::nothrow) unsigned char[cfg->layers]();
-    if (!t->blocks || !t->set) { ov_tower_destroy(t); return nullptr; }
+    t->fp8 = new (std::nothrow) ov_block_fp8[cfg->layers]();
+    t->set8 = new (std::nothrow) unsigned char[cfg->layers]();
+    if (!t->blocks || !t->set || !t->fp8 || !t->set8) { ov_tower_destroy(t); return nullptr; }
     return t;
 }
 
@@ -172,6 +176,8 @@ extern "C" void ov_tower_destroy(ov_tower* t) {
     if (!t) return;
     delete[] t->blocks;
     delete[] t->set;
+    delete[] t->fp8;
+    delete[] t->set8;
     delete t;
 }
 
@@ -188,11 +194,34 @@ extern "C" int ov_tower_set_block(ov_tower* t, int layer, const ov_block_weights
     return OV_OK;
 }
 
+namespace {
+bool tower_fp8(const ov_tower* t) {
+    for (int i = 0; i < t->cfg.layers; ++i)
+        if (!t->set8[i]) return false;
+    return true;
+}
+}  // namespace
+
+extern "C" int ov_tower_set_block_fp8(ov_tower* t, int layer, const ov_block_fp8* q) {
+    if (!t || layer < 0 || layer >= t->cfg.layers) return OV_ERR_INVALID;
+    if (!q) { t->set8[layer] = 0; return OV_OK; }                 // NULL clears: back to the bf16 path
+    const int D = t->cfg.width, F = t->cfg.mlp_pad;
+    if (D % 128 || F % 128 || D < 384 || F < 384) return OV_ERR_UNSUPPORTED;      // K-tiles of 128 fp8 elements, at least three
+    const void* p[] = {q->qkv_w8, q->qkv_s, q->qkv_b, q->out_w8, q->out_s, q->fc_w8, q->fc_s, q->fc_b, q->proj_w8, q->proj_s};
+    for (const void* v : p)
+        if (!v || ((uintptr_t)v & 15)) return OV_ERR_INVALID;
+    t->fp8[layer] = *q;
+    t->set8[layer] = 1;
+    return OV_OK;
+}
+
 extern "C" size_t ov_tower_workspace_bytes(const ov_tower* t, int B, int L) {
     if (!t || B <= 0 || L <= 0) return 0;
     const size_t M = (size_t)B * L;
     const int D = t->cfg.width;
-    return align_up(M * D * 2, 256) + align_up(M * (size_t)max_i(3 * D, t->cfg.mlp_pad) * 2, 256) + align_up(M * 8, 256);
+    size_t n = align_up(M * D * 2, 256) + align_up(M * (size_t)max_i(3 * D, t->cfg.mlp_pad) * 2, 256) + align_up(M * 8, 256);
+    if (tower_fp8(t)) n += align_up(M * (size_t)max_i(D, t->cfg.mlp_pad), 256) + align_up(M * 4, 256);   // fp8 activations + row scales
+    return n;
 }
 
 namespace {
@@ -274,6 +303,38 @@ int tail_images(int B, int L) {
 }
 }  // namespace
 
+namespace {
+// The same block with fp8 (e4m3) GEMM operands (BASELINE.json config #5): LN -> row quantisation fused, attention in bf16,
+// the attention output and the MLP hidden re-quantised row by row in front of out-proj / c_proj.
+int run_block_fp8(const ov_tower_cfg& c, const ov_block_weights& w, const ov_block_fp8& q, ov_bf16* x, ov_bf16* h, ov_bf16* big,
+                  unsigned char* q8, float* qs, int B, int L, ov_stream_t stream, bool prof) {
+    const int D = c.width, H = c.heads, hd = D / H, F = c.mlp_pad;
+    const int64_t M = (int64_t)B * L;
+    const int ldb = 3 * D > F ? 3 * D : F;
+    const float scale = 1.0f / sqrtf((float)hd);
+    const int gelu = c.gelu_tanh ? OV_EPI_BIAS_GELU_TANH : OV_EPI_BIAS_GELU_ERF;
+    const int fc_cls = c.gelu_tanh ? OV_PROF_GEMM_FC_TANH : OV_PROF_GEMM_FC;
+    int rc;
+#define OV_STEP(cls, call)                                           \
+    do {                                                             \
+        if (prof) { ProfScope ps__(cls, stream, M); rc = (call); }   \
+        else rc = (call);                                            \
+        if (rc) return rc;                                           \
+    } while (0)
+    OV_STEP(OV_PROF_LN, ov_layernorm_quant_fp8(x, D, w.ln1_w, w.ln1_b, q8, D, qs, M, D, c.ln_eps, stream));
+    OV_STEP(OV_PROF_GEMM_QKV, ov_gemm_fp8(q8, D, q.qkv_w8, D, qs, q.qkv_s, q.qkv_b, big, ldb, M, 3 * D, D, OV_EPI_BIAS, nullptr, 0, stream));
+    OV_STEP(OV_PROF_ATTN, ov_attention(big, ldb, h, D, B, L, H, hd, scale, stream));
+    OV_STEP(OV_PROF_LN, ov_quant_rows_fp8(h, D, q8, D, qs, M, D, stream));
+    OV_STEP(OV_PROF_GEMM_OUT, ov_gemm_fp8(q8, D, q.out_w8, D, qs, q.out_s, w.out_b, x, D, M, D, D, OV_EPI_BIAS_RESIDUAL, x, D, stream));
+    OV_STEP(OV_PROF_LN, ov_layernorm_quant_fp8(x, D, w.ln2_w, w.ln2_b, q8, D, qs, M, D, c.ln_eps, stream));
+    OV_STEP(fc_cls, ov_gemm_fp8(q8, D, q.fc_w8, D, qs, q.fc_s, q.fc_b, big, ldb, M, F, D, gelu, nullptr, 0, stream));
+    OV_STEP(OV_PROF_LN, ov_quant_rows_fp8(big, ldb, q8, F, qs, M, F, stream));
+    OV_STEP(OV_PROF_GEMM_PROJ, ov_gemm_fp8(q8, F, q.proj_w8, F, qs, q.proj_s, w.proj_b, x, D, M, D, F, OV_EPI_BIAS_RESIDUAL, x, D, stream));
+#undef OV_STEP
+    return OV_OK;
+}
+}  // namespace
+
 // x[B*L, D] is updated in place through all blocks.  When B*L leaves a few 256-row tiles over a whole number of rounds
 // (L/14 at B = 256: 257 tiles -> the out-proj / c_proj GEMMs need a 5th round for 4 of their 1028 tiles), the last
 // image(s) are peeled off and run, layer by layer, on an internal side stream: rows are independent through LN/GEMM and
@@ -305,12 +366,19 @@ extern "C" int ov_tower_forward(const ov_tower* t, ov_bf16* x, int B, int L, voi
         if (e != hipSuccess) return OV_ERR_HIP - (int)e;
     }
     const int64_t off = (int64_t)Bm * L;
+    const bool fp8 = tower_fp8(t);
+    const int qw = D > c.mlp_pad ? D : c.mlp_pad;                 // row pitch reserved per token in the fp8 activation buffer
+    unsigned char* q8 = (unsigned char*)stats + align_up((size_t)M * 8, 256);
+    float* qs = (float*)(q8 + align_up((size_t)M * qw, 256));
     for (int i = 0; i < c.layers; ++i) {
-        int rc = run_block(c, t->blocks[i], x, h, big, stats, Bm, L, stream, true);
+        int rc = fp8 ? run_block_fp8(c, t->blocks[i], t->fp8[i], x, h, big, q8, qs, Bm, L, stream, true)
+                     : run_block(c, t->blocks[i], x, h, big, stats, Bm, L, stream, true);
         if (rc) return rc;
         if (nt > 0) {
-            rc = run_block(c, t->blocks[i], x + off * D, h + off * D, big + off * ldb, stats + 2 * off, nt, L,
-                           (ov_stream_t)tc->stream, false);
+            rc = fp8 ? run_block_fp8(c, t->blocks[i], t->fp8[i], x + off * D, h + off * D, big + off * ldb, q8 + off * qw, qs + off,
+                                     nt, L, (ov_stream_t)tc->stream, false)
+                     : run_block(c, t->blocks[i], x + off * D, h + off * D, big + off * ldb, stats + 2 * off, nt, L,
+                                 (ov_stream_t)tc->stream, false);
             if (rc) return rc;
         }
     }

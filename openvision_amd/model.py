@@ -267,6 +267,7 @@ class ResidualAttentionBlock(nn.Module):
         self.gelu_tanh = gelu_is_tanh(act_kwargs)
         self.mlp_dim, self.mlp_pad = mlp, _round_up(mlp, 64)
         self._fold_pk = _Packed()
+        self._fp8_pk = _Packed()
 
     def packed_block(self, fold_ln: bool = True):
         """Device weights of this block in the kernels' layout.  With ``fold_ln`` (default; ``OVHIP_NO_LN_FOLD=1`` disables)
@@ -299,6 +300,32 @@ class ResidualAttentionBlock(nn.Module):
         keep = (g1, b1, wq, cq, wo, bo, g2, b2, wf, cf, wp, bp, sq, sf)
         return _lib.BlockWeights(*[C.c_void_p(t.data_ptr()) for t in keep]), keep
 
+    def packed_block_fp8(self):
+        """fp8 (OCP e4m3) copies of the four weight matrices for the fp8 path (BASELINE.json config #5): per-output-row absmax
+        scaling (scale = max|w_row| / 448), zero padding as in the bf16 layout; biases as the module holds them."""
+        d = self.attn.embed_dim
+        dev = self.attn.in_proj_weight.device
+
+        def q8(w, n_pad, k_pad):
+            w32 = torch.zeros(n_pad, k_pad, dtype=torch.float32, device=dev)
+            w32[: w.shape[0], : w.shape[1]] = w.detach().float()
+            scale = (w32.abs().amax(dim=1) / 448.0).clamp_min(1e-30)
+            return (w32 / scale[:, None]).to(torch.float8_e4m3fn).view(torch.uint8).contiguous(), scale.contiguous()
+
+        def build():
+            wq, sq = q8(self.attn.in_proj_weight, 3 * d, d)
+            wo, so = q8(self.attn.out_proj.weight, d, d)
+            wf, sf = q8(self.mlp.c_fc.weight, self.mlp_pad, d)
+            wp, sp = q8(self.mlp.c_proj.weight, d, self.mlp_pad)
+            bq = _pack_vec(self.attn.in_proj_bias, 3 * d, dev)
+            bf = _pack_vec(self.mlp.c_fc.bias, self.mlp_pad, dev)
+            return (wq, sq, bq, wo, so, wf, sf, bf, wp, sp)
+
+        key = (self.attn.in_proj_weight, self.attn.in_proj_bias, self.attn.out_proj.weight, self.mlp.c_fc.weight,
+               self.mlp.c_fc.bias, self.mlp.c_proj.weight)
+        keep = self._fp8_pk.get(key, build)
+        return _lib.BlockFp8(*[C.c_void_p(t.data_ptr()) for t in keep]), keep
+
     def forward(self, q_x: torch.Tensor, k_x=None, v_x=None, attn_mask=None) -> torch.Tensor:
         if k_x is not None or v_x is not None or attn_mask is not None:
             raise NotImplementedError("OpenVision blocks are unmasked self-attention (no k_x/v_x/attn_mask)")
@@ -308,7 +335,7 @@ class ResidualAttentionBlock(nn.Module):
 class _TowerHandle:
     """ov_tower handle + the packed tensors it borrows (kept alive here)."""
 
-    def __init__(self, blocks):
+    def __init__(self, blocks, fp8: bool = False):
         lib = _lib.load()
         b0 = blocks[0]
         d = b0.attn.embed_dim
@@ -323,7 +350,11 @@ class _TowerHandle:
             bw, keep = blk.packed_block(fold_ln=os.environ.get("OVHIP_NO_LN_FOLD", "0") != "1")
             self.keep.append(keep)
             check(lib.ov_tower_set_block(self.handle, i, C.byref(bw)), "ov_tower_set_block")
-        self.width, self.layers = d, len(blocks)
+            if fp8:
+                b8, keep8 = blk.packed_block_fp8()
+                self.keep.append(keep8)
+                check(lib.ov_tower_set_block_fp8(self.handle, i, C.byref(b8)), "ov_tower_set_block_fp8")
+        self.width, self.layers, self.fp8 = d, len(blocks), fp8
 
     def __del__(self):
         try:
@@ -341,12 +372,23 @@ def _block_params(blocks):
     return ps
 
 
+def default_precision() -> str:
+    """GEMM operand precision of the block stacks: "bf16" (default) or "fp8" (OVHIP_PRECISION=fp8; e4m3 weights and
+    activations on the MX-scaled MFMA, BASELINE.json config #5)."""
+    p = os.environ.get("OVHIP_PRECISION", "bf16").lower()
+    if p not in ("bf16", "fp8"):
+        raise ValueError(f"OVHIP_PRECISION={p!r}: expected bf16 or fp8")
+    return p
+
+
 class _TowerCache:
     def __init__(self):
         self._pk = _Packed()
+        self.precision = default_precision()
 
     def get(self, blocks) -> _TowerHandle:
-        return self._pk.get(_block_params(blocks), lambda: _TowerHandle(blocks))
+        fp8 = self.precision == "fp8"
+        return self._pk.get(_block_params(blocks), lambda: _TowerHandle(blocks, fp8=fp8), extra=(fp8,))
 
 
 def _run_blocks(blocks, x: torch.Tensor, cache: Optional[_TowerCache] = None, ws: Optional[_Workspace] = None):
@@ -384,6 +426,12 @@ class Transformer(nn.Module):
 
     def tower(self) -> _TowerHandle:
         return self._cache.get(list(self.resblocks))
+
+    def set_precision(self, precision: str) -> None:
+        """"bf16" or "fp8": operand precision of this stack's four GEMMs per block (the tower is re-packed on next use)."""
+        if precision not in ("bf16", "fp8"):
+            raise ValueError("precision must be 'bf16' or 'fp8'")
+        self._cache.precision = precision
 
     def forward(self, x: torch.Tensor, attn_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
         if attn_mask is not None:
@@ -562,6 +610,12 @@ class CLIP(nn.Module):
                              self.ln_final.bias, self.text_projection), build)
 
     # -- reference API -----------------------------------------------------------------------------------
+    def set_precision(self, precision: str) -> None:
+        """GEMM operand precision of both block stacks: "bf16" (default) or "fp8" (e4m3 weights and activations on the MX-scaled
+        MFMA; embedding, heads, attention, LayerNorm statistics and the loss stay as they are)."""
+        self.visual.transformer.set_precision(precision)
+        self.transformer.set_precision(precision)
+
     def encode_image(self, image: torch.Tensor, normalize: bool = False) -> torch.Tensor:
         """model.py:265-267.  Returns fp32 [B, embed_dim]."""
         return self.visual._encode(image, normalize)

@@ -85,3 +85,17 @@ def gemm_fp8(aq, wq, rowscale, colscale, bias=None, epi=0, resid=None):
                           ptr(bias) if bias is not None else None, ptr(out), out.stride(0), m, n, k, epi,
                           ptr(resid) if resid is not None else None, resid.stride(0) if resid is not None else 0, stream_ptr()))
     return out
+
+
+def quant_rows_fp8(x, gamma=None, beta=None, eps=1e-6):
+    """bf16 [rows, D] -> (uint8 e4m3 [rows, D], fp32 scales); with gamma/beta: LayerNorm first."""
+    lib = _lib.load()
+    rows, d = x.shape
+    q = torch.empty(rows, d, dtype=torch.uint8, device=x.device)
+    sc = torch.empty(rows, dtype=torch.float32, device=x.device)
+    if gamma is None:
+        check(lib.ov_quant_rows_fp8(ptr(x), x.stride(0), ptr(q), q.stride(0), ptr(sc), rows, d, stream_ptr()))
+    else:
+        check(lib.ov_layernorm_quant_fp8(ptr(x), x.stride(0), ptr(gamma), ptr(beta), ptr(q), q.stride(0), ptr(sc), rows, d, eps,
+                                         stream_ptr()))
+    return q, sc

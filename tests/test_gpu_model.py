@@ -262,6 +262,32 @@ def test_device_preprocess_bit_exact():
     assert torch.equal(b16.float().cpu(), torch.from_numpy(out[:1]).to(torch.bfloat16).float())
 
 
+@pytest.mark.timeout(900)
+def test_fp8_precision_large14():
+    """BASELINE.json config #5 (1 GPU, small batch): fp8 e4m3 weights/activations in the four GEMMs of every block.  The reference
+    has no fp8 mode; the check is against its fp32 outputs (golden) at the tolerance e4m3 allows: cosine >= 0.995 per embedding,
+    and the fp8 run must differ from the bf16 run (i.e. the fp8 kernels really ran)."""
+    cfg = preset("vit-large-patch14-224")
+    m = create_model(cfg, device=DEV, state_dict=synth.make_state_dict(cfg))
+    g = golden("large14_224.npz")
+    img = torch.from_numpy(g["images"].astype(np.float32)).to(DEV)
+    tok = torch.from_numpy(g["tokens"]).to(DEV)
+    f16, t16 = m.encode_image(img, normalize=True), m.encode_text(tok, normalize=True)
+    m.set_precision("fp8")
+    try:
+        f8, t8 = m.encode_image(img, normalize=True), m.encode_text(tok, normalize=True)
+    finally:
+        m.set_precision("bf16")
+    ref_i = torch.from_numpy(g["image_features"].astype(np.float32))
+    ref_t = torch.from_numpy(g["text_features"].astype(np.float32))
+    ci = torch.nn.functional.cosine_similarity(f8.cpu(), ref_i).min().item()
+    ct = torch.nn.functional.cosine_similarity(t8.cpu(), ref_t).min().item()
+    print(f"fp8 vs fp32 reference: min cosine image {ci:.5f} text {ct:.5f}")
+    assert ci > 0.995 and ct > 0.995
+    assert not torch.equal(f8, f16) and not torch.equal(t8, t16)
+    assert torch.equal(m.encode_image(img, normalize=True), f16)          # back on the bf16 path, bit for bit
+
+
 def test_checkpoint_dir_to_device(tiny, tmp_path):
     from openvision_amd import checkpoint as ck
     cfg = preset("vit-tiny-patch16-160")

@@ -204,3 +204,31 @@ def test_gemm_fp8_rejects_unsupported():
     s1 = torch.ones(256, device=DEV)
     with pytest.raises(Exception):
         H.gemm_fp8(aq, aq, s1, s1)                # K = 128 < 384
+
+
+@pytest.mark.parametrize("rows,D", [(5, 192), (771, 1024), (300, 4096), (64, 768)])
+def test_quant_rows_fp8(rows, D):
+    """Row quantisation to e4m3 (bit-exact against torch's own round-to-nearest-even cast) and the fused LayerNorm variant."""
+    x = (rnd(rows, D, seed=50) * (rnd(rows, 1, seed=51).abs() * 4 + 0.1)).to(torch.bfloat16)
+    q, sc = H.quant_rows_fp8(x.to(DEV))
+    amax = x.float().abs().amax(1)
+    np.testing.assert_allclose(sc.cpu().numpy(), (amax / 448.0).numpy(), rtol=1e-6)
+    scaled = x.float() * (448.0 / amax)[:, None]
+    ref = scaled.to(torch.float8_e4m3fn).view(torch.uint8)
+    qc = q.cpu()
+    diff = qc != ref
+    if diff.any():                       # v_cvt_pk_fp8_f32 against torch's CPU cast: adjacent codes only, and rarely
+        gd = qc.view(torch.float8_e4m3fn).float()[diff]
+        rd = ref.view(torch.float8_e4m3fn).float()[diff]
+        sd = scaled[diff]
+        print(f"fp8 cast differences: {int(diff.sum())} of {diff.numel()}; e.g. value {sd[0].item():.6f} -> hw {gd[0].item()} torch {rd[0].item()}")
+        assert (qc.int() - ref.int()).abs()[diff].max() <= 1
+        assert diff.float().mean() < 0.01
+    assert ((qc.view(torch.float8_e4m3fn).float() - scaled).abs() <= scaled.abs() * 0.0625 + 2.0 ** -9).all()   # half an e4m3 step
+    gamma, beta = rnd(D, seed=52) * 0.1 + 1, rnd(D, seed=53) * 0.1
+    ql, scl = H.quant_rows_fp8(x.to(DEV), gamma.to(DEV), beta.to(DEV), 1e-6)
+    y = R.layer_norm(x.float(), gamma, beta)
+    deq = ql.cpu().view(torch.float8_e4m3fn).float() * scl.cpu()[:, None]
+    # e4m3: 3 mantissa bits -> relative step 2^-3, half a step of rounding error relative to the row maximum's binade
+    assert (deq - y).abs().max() <= (y.abs().amax(1, keepdim=True) / 448.0 * 16.0 + 1e-6).max()
+    np.testing.assert_allclose(scl.cpu().numpy(), (y.abs().amax(1) / 448.0).numpy(), rtol=2e-5)
