@@ -112,6 +112,11 @@ def cpu_baseline(cfg, sd, budget_s: float):
 
 def main():
     a = parse()
+    # stdout carries exactly ONE line, the JSON result: libraries that print to fd 1 (RCCL's banner when a communicator is
+    # created, ...) are sent to stderr for the rest of the run; the result goes to a private duplicate of the original stdout.
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -247,7 +252,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg, sd, a.cpu_seconds)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        result_out.write(json.dumps(out) + "\n")
+        result_out.flush()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
