@@ -147,11 +147,21 @@ int ov_gemm_fp8(const unsigned char* A, int64_t lda, const unsigned char* W, int
                 const float* colscale, const float* bias, ov_bf16* C, int64_t ldc, int64_t M, int N, int K, int epilogue,
                 const ov_bf16* R, int64_t ldr, ov_stream_t stream);
 
+/* ov_gemm_fp8 with a STATIC activation scale on one side (scale = 2 * amax / 448, amax a calibrated device scalar):
+ * out_amax != NULL: C is e4m3 bytes [M, N] (ldc in bytes, % 16; N % 16 == 0) quantised with out_amax's scale, epilogue
+ *                   OV_EPI_BIAS_GELU_ERF / _TANH -- the c_fc -> c_proj hand-over without a bf16 round trip and a re-quantisation pass;
+ * in_amax  != NULL: every row of A carries in_amax's scale (rowscale ignored), epilogue OV_EPI_BIAS_RESIDUAL, C / R bf16.
+ * Exactly one of the two is set. */
+int ov_gemm_fp8_static(const unsigned char* A, int64_t lda, const unsigned char* W, int64_t ldw, const float* rowscale,
+                       const float* in_amax, const float* colscale, const float* bias, void* C, int64_t ldc, const float* out_amax,
+                       int64_t M, int N, int K, int epilogue, const ov_bf16* R, int64_t ldr, ov_stream_t stream);
+
 /* Activation quantisation for ov_gemm_fp8: q[r,:] = e4m3(y[r,:] / s_r), s_r = max|y[r,:]| / 448, with y = x (ov_quant_rows_fp8) or
  * y = LayerNorm(x) * gamma + beta in fp32 (ov_layernorm_quant_fp8; eps, biased variance as transformer.py:15-30).  x bf16
  * [rows, D] (ldx), q bytes [rows, D] (ldq, % 8), rowscale [rows] fp32.  D % 8 == 0, D <= 8192. */
+/* amax_acc (device float, may be NULL): running maximum of |x| over every row quantised so far (calibration of static scales). */
 int ov_quant_rows_fp8(const ov_bf16* x, int64_t ldx, unsigned char* q, int64_t ldq, float* rowscale, int64_t rows, int D,
-                      ov_stream_t stream);
+                      float* amax_acc, ov_stream_t stream);
 int ov_layernorm_quant_fp8(const ov_bf16* x, int64_t ldx, const float* gamma, const float* beta, unsigned char* q, int64_t ldq,
                            float* rowscale, int64_t rows, int D, float eps, ov_stream_t stream);
 
@@ -246,6 +256,10 @@ int       ov_tower_set_block(ov_tower* t, int layer, const ov_block_weights* w);
  * with row quantisation, fp8 GEMMs (ov_gemm_fp8), bf16 attention, row re-quantisation in front of out_proj / c_proj.  Needs
  * width and mlp_pad % 128 == 0 and >= 384.  ov_tower_workspace_bytes grows accordingly: query it after setting the copies. */
 int       ov_tower_set_block_fp8(ov_tower* t, int layer, const ov_block_fp8* q);
+/* Static scale of the MLP hidden in the fp8 path.  h_amax: device float[layers] (borrowed).  mode 0: off (the hidden is written in
+ * bf16 and re-quantised row by row); 1: same, and the running maximum of |hidden| per layer is recorded into h_amax (calibration);
+ * 2: c_fc writes the hidden directly as e4m3 with the scale 2 * h_amax[layer] / 448 and c_proj reads it with that scale. */
+int       ov_tower_set_fp8_hidden_scale(ov_tower* t, float* h_amax, int mode);
 size_t    ov_tower_workspace_bytes(const ov_tower* t, int B, int L);
 /* x[B*L, D] bf16 is updated in place through all `layers` blocks. */
 int       ov_tower_forward(const ov_tower* t, ov_bf16* x, int B, int L, void* workspace,

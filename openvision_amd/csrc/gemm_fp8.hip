@@ -41,13 +41,20 @@ struct Fp8Args {
     ov_bf16* C; const ov_bf16* R;
     int64_t lda, ldw, ldc, ldr, M;
     int N, K, tiles_m, tiles_n;
+    const float* amax_in;      // MODE 2: every row of A was quantised with the scale HEADROOM * (*amax_in) / 448 (rowscale unused)
+    const float* amax_out;     // MODE 1: C is written as e4m3 bytes with that static scale of its own
 };
+
+constexpr float HEADROOM = 2.0f;   // static activation scales leave one binade above the calibrated maximum (e4m3 is floating point:
+                                   // head room costs range at the bottom, not precision)
 
 template <int V> struct IntC { static constexpr int value = V; };
 
-template <int EPI>
+// MODE 0: per-row scales from the parameter block, bf16 output.  MODE 1: same, output quantised to e4m3 with the static scale
+// HEADROOM * amax_out / 448 (feeds the next fp8 GEMM without a bf16 round trip).  MODE 2: one static input scale, bf16 output.
+template <int EPI, int MODE>
 __device__ __forceinline__ void epilogue_fp8(const Fp8Args& g, f32x4_t (&acc)[8][4], char* img, const char* prm, int64_t m0, int n0,
-                                             int wave, int lane, bool edge) {
+                                             int wave, int lane, bool edge, float rs_const, float inv_out) {
     const int wm = wave >> 2, wn = wave & 3;
     const int fr = lane & 15, fq = lane >> 4;
     const int er = lane >> 3, ec = lane & 7;
@@ -112,7 +119,7 @@ __device__ __forceinline__ void epilogue_fp8(const Fp8Args& g, f32x4_t (&acc)[8]
             for (int k = 4; k < 8; ++k) load_resid(k);
         }
         if (i < 8) {
-            const f32x2_t rs = {rsq[i], rsq[i]};
+            const f32x2_t rs = {MODE == 2 ? rs_const : rsq[i], MODE == 2 ? rs_const : rsq[i]};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 f32x2_t v01 = f32x2_t{acc[i][j][0], acc[i][j][1]} * rs;
@@ -123,24 +130,44 @@ __device__ __forceinline__ void epilogue_fp8(const Fp8Args& g, f32x4_t (&acc)[8]
                 v23 = __builtin_elementwise_fma(v23, f32x2_t{cq[j][2], cq[j][3]}, b23);
                 if (EPI == OV_EPI_BIAS_GELU_ERF) gelu_erf_f2x2(v01, v23);
                 if (EPI == OV_EPI_BIAS_GELU_TANH) { v01 = gelu_tanh_f2(v01); v23 = gelu_tanh_f2(v23); }
-                const u32x2_t pk = {pack_bf16x2(v01[0], v01[1]), pack_bf16x2(v23[0], v23[1])};
-                *(u32x2_t*)(wr + (((j * 2 + (fq >> 1)) ^ wsw) << 4)) = pk;
+                if (MODE == 1) {
+                    // 4 consecutive n -> 4 e4m3 bytes; image rows are 64 B (16 dwords), chunk ^= (row >> 1) & 3
+                    const f32x2_t io = {inv_out, inv_out};
+                    v01 *= io; v23 *= io;
+                    int pk8 = 0;
+                    pk8 = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(v01[0], -448.f, 448.f), __builtin_amdgcn_fmed3f(v01[1], -448.f, 448.f), pk8, false);
+                    pk8 = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(v23[0], -448.f, 448.f), __builtin_amdgcn_fmed3f(v23[1], -448.f, 448.f), pk8, true);
+                    *(int*)(img + fr * 64 + ((j ^ ((fr >> 1) & 3)) << 4) + fq * 4) = pk8;
+                } else {
+                    const u32x2_t pk = {pack_bf16x2(v01[0], v01[1]), pack_bf16x2(v23[0], v23[1])};
+                    *(u32x2_t*)(wr + (((j * 2 + (fq >> 1)) ^ wsw) << 4)) = pk;
+                }
             }
         }
-        if (EPI == OV_EPI_BIAS_RESIDUAL) {
-            if (i == 4) { wait_resid(0, 4, 8); put(0); put(1); put(2); put(3); }
-            else if (i > 4) { wait_resid(i - 1, i, 14); put(i - 1); }
-        } else if (i > 0) {
-            put(i - 1);
-        }
-        if (i < 8) {
-            vo[i][0] = *(const u32x4_t*)(rd);
-            vo[i][1] = *(const u32x4_t*)(rd + 1024);
+        if (MODE == 1) {
+            // 16 rows x 64 bytes: lane -> row lane >> 2, 16-byte chunk lane & 3 (one read, one 16-byte store per pass)
+            if (i > 0) {
+                const unsigned m = (unsigned)m0 + wm * 128 + (i - 1) * 16 + (lane >> 2);
+                const int n8 = n0 + wn * 64 + (lane & 3) * 16;
+                if (m < (unsigned)g.M && n8 < g.N) *(u32x4_t*)((unsigned char*)g.C + (int64_t)m * g.ldc + n8) = vo[i - 1][0];
+            }
+            if (i < 8) vo[i][0] = *(const u32x4_t*)(img + (lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 3) & 3)) << 4));
+        } else {
+            if (EPI == OV_EPI_BIAS_RESIDUAL) {
+                if (i == 4) { wait_resid(0, 4, 8); put(0); put(1); put(2); put(3); }
+                else if (i > 4) { wait_resid(i - 1, i, 14); put(i - 1); }
+            } else if (i > 0) {
+                put(i - 1);
+            }
+            if (i < 8) {
+                vo[i][0] = *(const u32x4_t*)(rd);
+                vo[i][1] = *(const u32x4_t*)(rd + 1024);
+            }
         }
     }
 }
 
-template <int EPI>
+template <int EPI, int MODE>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_fp8_persist(const Fp8Args g) {
     __shared__ __attribute__((aligned(16))) char smem[SMEM_TOTAL];
     const int tid = threadIdx.x;
@@ -216,13 +243,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_fp8_persist(const Fp8Args g)
         c = c + 4 <= g.N ? c : g.N - 4;
         if (wave == 0 && g.bias != nullptr) __builtin_amdgcn_global_load_lds((gptr_t)(g.bias + c), (lptr_t)dst, 16, 0, 0);
         if (wave == 1) __builtin_amdgcn_global_load_lds((gptr_t)(g.colscale + c), (lptr_t)(dst + 1024), 16, 0, 0);
-        if (wave >= 4) {                                             // 256 row scales: 4 waves x 64 dwords (clamped rows stay in bounds)
+        if (MODE != 2 && wave >= 4) {                                // 256 row scales: 4 waves x 64 dwords (clamped rows stay in bounds)
             int64_t r = mm + (wave - 4) * 64 + lane;
             r = r < g.M ? r : g.M - 1;
             __builtin_amdgcn_global_load_lds((gptr_t)(g.rowscale + r), (lptr_t)(dst + 2048 + (wave - 4) * 256), 4, 0, 0);
         }
     };
 
+    const float rs_const = MODE == 2 ? HEADROOM * (1.0f / 448.0f) * *g.amax_in : 0.f;
+    const float inv_out = MODE == 1 ? 448.0f / (HEADROOM * fmaxf(*g.amax_out, 1e-30f)) : 0.f;
     const int wm = wave >> 2, wn = wave & 3;
     const int fr = lane & 15, fq = lane >> 4;
     // fragment reads: operand row `row` of a piece, logical chunks 2 fq and 2 fq + 1 -> physical chunk ^ (row & 7) = ^ (fr & 7)
@@ -275,6 +304,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_fp8_persist(const Fp8Args g)
             if (KIND == 0) {
                 if (p == 3) {
                     if (strict) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    else if (MODE == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // byte output: 8 stores per wave and tile
                     else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
                 }
             } else if (KIND == 1) {
@@ -334,7 +364,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_fp8_persist(const Fp8Args g)
         }
         __builtin_amdgcn_sched_barrier(0);
         const bool edge = (m0 + BM > g.M) || (n0 + BN > g.N);
-        epilogue_fp8<EPI>(g, acc, smem + IMG_OFF + wave * 2048, smem + PRM_OFF + pslot * 4096, m0, n0, wave, lane, edge);
+        epilogue_fp8<EPI, MODE>(g, acc, smem + IMG_OFF + wave * 2048, smem + PRM_OFF + pslot * 4096, m0, n0, wave, lane, edge, rs_const,
+                                inv_out);
         if (!has_next) break;
         strict = edge;
         __builtin_amdgcn_sched_barrier(0);
@@ -359,11 +390,22 @@ int num_cus_fp8() {
     return n;
 }
 
-template <int EPI>
+template <int EPI, int MODE>
 int launch_fp8(const Fp8Args& a, hipStream_t st) {
     const int nwg = a.tiles_m * a.tiles_n, ncu = num_cus_fp8();
-    hipLaunchKernelGGL(gemm_fp8_persist<EPI>, dim3(nwg < ncu ? nwg : ncu), dim3(NTHREADS), 0, st, a);
+    hipLaunchKernelGGL((gemm_fp8_persist<EPI, MODE>), dim3(nwg < ncu ? nwg : ncu), dim3(NTHREADS), 0, st, a);
     OV_LAUNCH_CHECK();
+    return OV_OK;
+}
+
+int check_fp8(const void* A, int64_t lda, const void* W, int64_t ldw, const void* C, int64_t ldc, int64_t M, int N, int K) {
+    if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return OV_ERR_INVALID;
+    if (K % BKB || K < 3 * BKB || N % 8 || lda % 16 || ldw % 16 || ldc % 8) return OV_ERR_UNSUPPORTED;
+    if (lda < K || ldw < K || ldc < N) return OV_ERR_INVALID;
+    if (((uintptr_t)A | (uintptr_t)W | (uintptr_t)C) & 15) return OV_ERR_INVALID;
+    const int64_t tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    if (tiles_m * tiles_n > 0x7fffffffLL || M > 0x7fff0000LL) return OV_ERR_UNSUPPORTED;
+    if ((int64_t)BM * lda > 0x7fffffffLL || (int64_t)BN * ldw > 0x7fffffffLL) return OV_ERR_UNSUPPORTED;   // 32-bit in-tile offsets
     return OV_OK;
 }
 
@@ -372,22 +414,45 @@ int launch_fp8(const Fp8Args& a, hipStream_t st) {
 extern "C" int ov_gemm_fp8(const unsigned char* A, int64_t lda, const unsigned char* W, int64_t ldw, const float* rowscale,
                            const float* colscale, const float* bias, ov_bf16* C, int64_t ldc, int64_t M, int N, int K,
                            int epilogue, const ov_bf16* R, int64_t ldr, ov_stream_t stream) {
-    if (!A || !W || !C || !rowscale || !colscale || M <= 0 || N <= 0 || K <= 0) return OV_ERR_INVALID;
-    if (K % BKB || K < 3 * BKB || N % 8 || lda % 16 || ldw % 16 || ldc % 8) return OV_ERR_UNSUPPORTED;
-    if (lda < K || ldw < K || ldc < N) return OV_ERR_INVALID;
-    if (((uintptr_t)A | (uintptr_t)W | (uintptr_t)C | (uintptr_t)colscale) & 15) return OV_ERR_INVALID;
+    int rc = check_fp8(A, lda, W, ldw, C, ldc, M, N, K);
+    if (rc) return rc;
+    if (!rowscale || !colscale || ((uintptr_t)colscale & 15)) return OV_ERR_INVALID;
     if (bias && ((uintptr_t)bias & 15)) return OV_ERR_INVALID;
     if (epilogue == OV_EPI_BIAS_RESIDUAL && (!R || ldr % 8 || ldr < N || ((uintptr_t)R & 15))) return OV_ERR_INVALID;
-    const int64_t tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-    if (tiles_m * tiles_n > 0x7fffffffLL || M > 0x7fff0000LL) return OV_ERR_UNSUPPORTED;
-    if ((int64_t)BM * lda > 0x7fffffffLL || (int64_t)BN * ldw > 0x7fffffffLL) return OV_ERR_UNSUPPORTED;   // 32-bit in-tile offsets
-    const Fp8Args a{A, W, bias, rowscale, colscale, C, R, lda, ldw, ldc, ldr, M, N, K, (int)tiles_m, (int)tiles_n};
+    const Fp8Args a{A, W, bias, rowscale, colscale, C, R, lda, ldw, ldc, ldr, M, N, K, (int)((M + BM - 1) / BM), (int)((N + BN - 1) / BN),
+                    nullptr, nullptr};
     hipStream_t st = (hipStream_t)stream;
     switch (epilogue) {
-        case OV_EPI_BIAS: return launch_fp8<OV_EPI_BIAS>(a, st);
-        case OV_EPI_BIAS_GELU_ERF: return launch_fp8<OV_EPI_BIAS_GELU_ERF>(a, st);
-        case OV_EPI_BIAS_GELU_TANH: return launch_fp8<OV_EPI_BIAS_GELU_TANH>(a, st);
-        case OV_EPI_BIAS_RESIDUAL: return launch_fp8<OV_EPI_BIAS_RESIDUAL>(a, st);
+        case OV_EPI_BIAS: return launch_fp8<OV_EPI_BIAS, 0>(a, st);
+        case OV_EPI_BIAS_GELU_ERF: return launch_fp8<OV_EPI_BIAS_GELU_ERF, 0>(a, st);
+        case OV_EPI_BIAS_GELU_TANH: return launch_fp8<OV_EPI_BIAS_GELU_TANH, 0>(a, st);
+        case OV_EPI_BIAS_RESIDUAL: return launch_fp8<OV_EPI_BIAS_RESIDUAL, 0>(a, st);
         default: return OV_ERR_UNSUPPORTED;
     }
+}
+
+// The same GEMM with a STATIC scale on one side (calibrated activation maximum, device scalar; scale = 2 * amax / 448):
+//   out_amax != NULL: C is written as e4m3 bytes C8[M, N] (ldc in bytes, % 16, N % 16 == 0) quantised with out_amax's scale
+//                     -- epilogue OV_EPI_BIAS_GELU_ERF / _TANH (the c_fc -> c_proj hand-over without a bf16 round trip);
+//   in_amax  != NULL: every row of A carries in_amax's scale (rowscale ignored) -- epilogue OV_EPI_BIAS_RESIDUAL.
+extern "C" int ov_gemm_fp8_static(const unsigned char* A, int64_t lda, const unsigned char* W, int64_t ldw, const float* rowscale,
+                                  const float* in_amax, const float* colscale, const float* bias, void* C, int64_t ldc,
+                                  const float* out_amax, int64_t M, int N, int K, int epilogue, const ov_bf16* R, int64_t ldr,
+                                  ov_stream_t stream) {
+    int rc = check_fp8(A, lda, W, ldw, C, ldc, M, N, K);
+    if (rc) return rc;
+    if (!colscale || ((uintptr_t)colscale & 15) || (bias && ((uintptr_t)bias & 15))) return OV_ERR_INVALID;
+    if ((in_amax != nullptr) == (out_amax != nullptr)) return OV_ERR_INVALID;          // exactly one static side
+    const Fp8Args a{A, W, bias, rowscale, colscale, (ov_bf16*)C, R, lda, ldw, ldc, ldr, M, N, K, (int)((M + BM - 1) / BM),
+                    (int)((N + BN - 1) / BN), in_amax, out_amax};
+    hipStream_t st = (hipStream_t)stream;
+    if (out_amax) {
+        if (!rowscale || N % 16 || ldc % 16) return OV_ERR_INVALID;
+        if (epilogue == OV_EPI_BIAS_GELU_ERF) return launch_fp8<OV_EPI_BIAS_GELU_ERF, 1>(a, st);
+        if (epilogue == OV_EPI_BIAS_GELU_TANH) return launch_fp8<OV_EPI_BIAS_GELU_TANH, 1>(a, st);
+        return OV_ERR_UNSUPPORTED;
+    }
+    if (epilogue != OV_EPI_BIAS_RESIDUAL) return OV_ERR_UNSUPPORTED;
+    if (!R || ldr % 8 || ldr < N || ((uintptr_t)R & 15)) return OV_ERR_INVALID;
+    return launch_fp8<OV_EPI_BIAS_RESIDUAL, 2>(a, st);
 }

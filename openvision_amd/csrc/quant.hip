@@ -19,7 +19,7 @@ __device__ __forceinline__ float wave_max(float v) {
 template <int NCH, bool LN>
 __global__ __launch_bounds__(256) void quant_rows(const ov_bf16* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
                                                  const float* __restrict__ beta, unsigned char* __restrict__ q, int64_t ldq,
-                                                 float* __restrict__ scale, int64_t rows, int D, float eps) {
+                                                 float* __restrict__ scale, int64_t rows, int D, float eps, float* __restrict__ amax_acc) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int nchunk = D >> 3;
@@ -91,18 +91,23 @@ __global__ __launch_bounds__(256) void quant_rows(const ov_bf16* __restrict__ x,
                 *(u32x2_t*)(q + row * ldq + ch * 8) = u32x2_t{(unsigned)lo, (unsigned)hi};
             }
         }
-        if (lane == 0) scale[row] = sc;
+        if (lane == 0) {
+            scale[row] = sc;
+            // calibration: running maximum over all rows (values >= 0: their bit patterns order like unsigned integers); the plain
+            // read skips the atomic once the maximum has settled
+            if (amax_acc != nullptr && amax > *(volatile float*)amax_acc) atomicMax((unsigned*)amax_acc, __float_as_uint(amax));
+        }
     }
 }
 
 template <bool LN>
 int launch_quant(const ov_bf16* x, int64_t ldx, const float* g, const float* b, unsigned char* q, int64_t ldq, float* scale,
-                 int64_t rows, int D, float eps, hipStream_t st) {
+                 int64_t rows, int D, float eps, float* amax_acc, hipStream_t st) {
     int64_t blocks = (rows + 3) / 4;
     if (blocks > 16384) blocks = 16384;
     const dim3 grid((unsigned)blocks), blk(256);
     const int nch = (D / 8 + 63) / 64;
-#define OV_Q(N) hipLaunchKernelGGL((quant_rows<N, LN>), grid, blk, 0, st, x, ldx, g, b, q, ldq, scale, rows, D, eps)
+#define OV_Q(N) hipLaunchKernelGGL((quant_rows<N, LN>), grid, blk, 0, st, x, ldx, g, b, q, ldq, scale, rows, D, eps, amax_acc)
     if (nch <= 1) OV_Q(1);
     else if (nch <= 2) OV_Q(2);
     else if (nch <= 3) OV_Q(3);
@@ -117,11 +122,11 @@ int launch_quant(const ov_bf16* x, int64_t ldx, const float* g, const float* b, 
 }  // namespace
 
 extern "C" int ov_quant_rows_fp8(const ov_bf16* x, int64_t ldx, unsigned char* q, int64_t ldq, float* rowscale, int64_t rows, int D,
-                                 ov_stream_t stream) {
+                                 float* amax_acc, ov_stream_t stream) {
     if (!x || !q || !rowscale || rows <= 0 || D <= 0) return OV_ERR_INVALID;
     if (D % 8 || D > 8192 || ldx % 8 || ldx < D || ldq % 8 || ldq < D) return OV_ERR_UNSUPPORTED;
     if (((uintptr_t)x & 15) || ((uintptr_t)q & 7)) return OV_ERR_INVALID;
-    return launch_quant<false>(x, ldx, nullptr, nullptr, q, ldq, rowscale, rows, D, 0.f, (hipStream_t)stream);
+    return launch_quant<false>(x, ldx, nullptr, nullptr, q, ldq, rowscale, rows, D, 0.f, amax_acc, (hipStream_t)stream);
 }
 
 extern "C" int ov_layernorm_quant_fp8(const ov_bf16* x, int64_t ldx, const float* gamma, const float* beta, unsigned char* q,
@@ -129,5 +134,5 @@ extern "C" int ov_layernorm_quant_fp8(const ov_bf16* x, int64_t ldx, const float
     if (!x || !q || !rowscale || !gamma || !beta || rows <= 0 || D <= 0) return OV_ERR_INVALID;
     if (D % 8 || D > 8192 || ldx % 8 || ldx < D || ldq % 8 || ldq < D) return OV_ERR_UNSUPPORTED;
     if (((uintptr_t)x & 15) || ((uintptr_t)q & 7) || (((uintptr_t)gamma | (uintptr_t)beta) & 15)) return OV_ERR_INVALID;
-    return launch_quant<true>(x, ldx, gamma, beta, q, ldq, rowscale, rows, D, eps, (hipStream_t)stream);
+    return launch_quant<true>(x, ldx, gamma, beta, q, ldq, rowscale, rows, D, eps, nullptr, (hipStream_t)stream);
 }

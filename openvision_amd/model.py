@@ -355,6 +355,19 @@ class _TowerHandle:
                 self.keep.append(keep8)
                 check(lib.ov_tower_set_block_fp8(self.handle, i, C.byref(b8)), "ov_tower_set_block_fp8")
         self.width, self.layers, self.fp8 = d, len(blocks), fp8
+        self.h_amax = None
+        if fp8:
+            # per-layer running maximum of the MLP hidden: recorded while the hidden is quantised row by row (mode 1), then the
+            # static scale of the fused c_fc -> c_proj hand-over (mode 2, freeze_fp8_scales)
+            self.h_amax = torch.zeros(len(blocks), dtype=torch.float32, device=b0.attn.in_proj_weight.device)
+            check(lib.ov_tower_set_fp8_hidden_scale(self.handle, ptr(self.h_amax), 1), "ov_tower_set_fp8_hidden_scale")
+
+    def freeze_fp8_scales(self) -> None:
+        if not self.fp8:
+            raise _lib.OvhipError("freeze_fp8_scales: the tower is not in fp8 precision")
+        if not bool((self.h_amax > 0).all()):
+            raise _lib.OvhipError("freeze_fp8_scales: run at least one forward in fp8 precision first (calibration)")
+        check(_lib.load().ov_tower_set_fp8_hidden_scale(self.handle, ptr(self.h_amax), 2), "ov_tower_set_fp8_hidden_scale")
 
     def __del__(self):
         try:
@@ -432,6 +445,11 @@ class Transformer(nn.Module):
         if precision not in ("bf16", "fp8"):
             raise ValueError("precision must be 'bf16' or 'fp8'")
         self._cache.precision = precision
+
+    def freeze_fp8_scales(self) -> None:
+        """fp8 precision: after at least one forward (which records the per-layer maximum of the MLP hidden), switch c_fc -> c_proj to
+        the fused hand-over with a static scale (2 x the recorded maximum / 448) -- no bf16 round trip of the hidden."""
+        self.tower().freeze_fp8_scales()
 
     def forward(self, x: torch.Tensor, attn_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
         if attn_mask is not None:
@@ -615,6 +633,11 @@ class CLIP(nn.Module):
         MFMA; embedding, heads, attention, LayerNorm statistics and the loss stay as they are)."""
         self.visual.transformer.set_precision(precision)
         self.transformer.set_precision(precision)
+
+    def freeze_fp8_scales(self) -> None:
+        """fp8 precision, after a calibration forward of both towers: static scales for the MLP hidden (see Transformer)."""
+        self.visual.transformer.freeze_fp8_scales()
+        self.transformer.freeze_fp8_scales()
 
     def encode_image(self, image: torch.Tensor, normalize: bool = False) -> torch.Tensor:
         """model.py:265-267.  Returns fp32 [B, embed_dim]."""

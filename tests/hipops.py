@@ -87,15 +87,29 @@ def gemm_fp8(aq, wq, rowscale, colscale, bias=None, epi=0, resid=None):
     return out
 
 
-def quant_rows_fp8(x, gamma=None, beta=None, eps=1e-6):
+def quant_rows_fp8(x, gamma=None, beta=None, eps=1e-6, amax=None):
     """bf16 [rows, D] -> (uint8 e4m3 [rows, D], fp32 scales); with gamma/beta: LayerNorm first."""
     lib = _lib.load()
     rows, d = x.shape
     q = torch.empty(rows, d, dtype=torch.uint8, device=x.device)
     sc = torch.empty(rows, dtype=torch.float32, device=x.device)
     if gamma is None:
-        check(lib.ov_quant_rows_fp8(ptr(x), x.stride(0), ptr(q), q.stride(0), ptr(sc), rows, d, stream_ptr()))
+        check(lib.ov_quant_rows_fp8(ptr(x), x.stride(0), ptr(q), q.stride(0), ptr(sc), rows, d,
+                                    ptr(amax) if amax is not None else None, stream_ptr()))
     else:
         check(lib.ov_layernorm_quant_fp8(ptr(x), x.stride(0), ptr(gamma), ptr(beta), ptr(q), q.stride(0), ptr(sc), rows, d, eps,
                                          stream_ptr()))
     return q, sc
+
+
+def gemm_fp8_static(aq, wq, colscale, bias, epi, rowscale=None, in_amax=None, out_amax=None, resid=None):
+    """out_amax: returns e4m3 bytes [m, n]; in_amax: returns bf16."""
+    lib = _lib.load()
+    m, k = aq.shape
+    n = wq.shape[0]
+    out = torch.empty(m, n, dtype=torch.uint8 if out_amax is not None else torch.bfloat16, device=aq.device)
+    check(lib.ov_gemm_fp8_static(ptr(aq), aq.stride(0), ptr(wq), wq.stride(0), ptr(rowscale) if rowscale is not None else None,
+                                 ptr(in_amax) if in_amax is not None else None, ptr(colscale), ptr(bias) if bias is not None else None,
+                                 ptr(out), out.stride(0), ptr(out_amax) if out_amax is not None else None, m, n, k, epi,
+                                 ptr(resid) if resid is not None else None, resid.stride(0) if resid is not None else 0, stream_ptr()))
+    return out

@@ -285,6 +285,18 @@ def test_fp8_precision_large14():
     print(f"fp8 vs fp32 reference: min cosine image {ci:.5f} text {ct:.5f}")
     assert ci > 0.995 and ct > 0.995
     assert not torch.equal(f8, f16) and not torch.equal(t8, t16)
+    # static scales for the MLP hidden (fused c_fc -> c_proj hand-over), calibrated by the forwards above
+    m.set_precision("fp8")
+    try:
+        m.encode_image(img); m.encode_text(tok)                           # calibration pass of the re-packed towers
+        m.freeze_fp8_scales()
+        f8s, t8s = m.encode_image(img, normalize=True), m.encode_text(tok, normalize=True)
+    finally:
+        m.set_precision("bf16")
+    cis = torch.nn.functional.cosine_similarity(f8s.cpu(), ref_i).min().item()
+    cts = torch.nn.functional.cosine_similarity(t8s.cpu(), ref_t).min().item()
+    print(f"fp8 static hidden scales vs fp32 reference: min cosine image {cis:.5f} text {cts:.5f}")
+    assert cis > 0.995 and cts > 0.995
     assert torch.equal(m.encode_image(img, normalize=True), f16)          # back on the bf16 path, bit for bit
 
 

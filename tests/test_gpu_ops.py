@@ -232,3 +232,29 @@ def test_quant_rows_fp8(rows, D):
     # e4m3: 3 mantissa bits -> relative step 2^-3, half a step of rounding error relative to the row maximum's binade
     assert (deq - y).abs().max() <= (y.abs().amax(1, keepdim=True) / 448.0 * 16.0 + 1e-6).max()
     np.testing.assert_allclose(scl.cpu().numpy(), (y.abs().amax(1) / 448.0).numpy(), rtol=2e-5)
+
+
+def test_gemm_fp8_static_scales():
+    """c_fc -> c_proj hand-over with a static scale: the first GEMM writes e4m3 bytes (scale 2 * amax / 448), the second reads them
+    with that scalar scale; both against fp32 arithmetic on the same quantised data."""
+    M, D_, F_ = 1000, 1024, 4096
+    a = rnd(M, D_, seed=60)
+    w1, b1 = rnd(F_, D_, seed=61) / D_ ** 0.5, rnd(F_, seed=62) * 0.1
+    w2, b2 = rnd(D_, F_, seed=63) / F_ ** 0.5, rnd(D_, seed=64) * 0.1
+    res = rnd(M, D_, seed=65).to(torch.bfloat16)
+    aq, rs = H.quantize_rows_e4m3(a.to(DEV)); w1q, c1 = H.quantize_rows_e4m3(w1.to(DEV)); w2q, c2 = H.quantize_rows_e4m3(w2.to(DEV))
+    deq = lambda q, s_: q.view(torch.float8_e4m3fn).float() * s_[:, None]
+    hid = torch.nn.functional.gelu(deq(aq, rs) @ deq(w1q, c1).T + b1.to(DEV))
+    amax = hid.abs().max().reshape(1).contiguous()
+    h8 = H.gemm_fp8_static(aq, w1q, c1, b1.to(DEV), 1, rowscale=rs, out_amax=amax)
+    sc = 2.0 * amax / 448.0
+    hq = h8.view(torch.float8_e4m3fn).float() * sc
+    assert (hq - hid).abs().max() <= hid.abs().max() * 0.07 + 1e-3              # e4m3 step relative to the element's own magnitude
+    # e4m3 half step (2^-4 relative; the hardware cast breaks near-ties downwards), one subnormal step, and the kernel's polynomial
+    # erf-GELU (|err| <= 1.4e-4 |x| on the pre-activation, here |x| < 8)
+    err, bound = (hq - hid).abs(), hid.abs() * 0.0725 + sc * 2.0 ** -9 * 1.01 + 1.2e-3
+    worst = (err - bound).argmax()
+    assert (err <= bound).all(), (hid.flatten()[worst].item(), hq.flatten()[worst].item(), sc.item())
+    out = H.gemm_fp8_static(h8, w2q, c2, b2.to(DEV), 3, in_amax=amax, resid=res.to(DEV)).float()
+    ref = hq @ deq(w2q, c2).T + b2.to(DEV) + res.to(DEV).float()
+    np.testing.assert_allclose(out.cpu().numpy(), ref.cpu().numpy(), rtol=1e-2, atol=2e-2)
