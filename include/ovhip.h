@@ -138,6 +138,11 @@ int ov_l2norm(const void* x, int x_dtype, int64_t ldx, float* y, int64_t ldy, in
 int ov_logits(const float* X, const float* Y, float* out, int64_t ldo, int n1, int n2, int E, float scale,
               ov_stream_t stream);
 
+/* ov_attention with the output written as e4m3 bytes out8[B*L, H*64] (ld_out in bytes) under the static scale 2 * (*out_amax) / 448
+ * (device scalar; fp8 path: the out-proj GEMM then reads it through ov_gemm_fp8_static).  head_dim 64; else OV_ERR_UNSUPPORTED. */
+int ov_attention_fp8out(const ov_bf16* qkv, int64_t ld_qkv, unsigned char* out8, int64_t ld_out, int B, int L, int H, int hd,
+                        float scale, const float* out_amax, ov_stream_t stream);
+
 /* ---- fp8 GEMM (BASELINE.json config #5: fp8 weights/activations on the CDNA4 fp8 MFMA) --------------------------------------
  * C = epilogue(rowscale[m] * colscale[n] * (A . W^T) + bias):  A [M, K], W [N, K] OCP e4m3fn bytes (K contiguous, lda/ldw in
  * bytes, % 16), rowscale [M] / colscale [N] fp32 dequantisation scales (per activation row / per weight row), bias fp32 or NULL,
@@ -256,10 +261,11 @@ int       ov_tower_set_block(ov_tower* t, int layer, const ov_block_weights* w);
  * with row quantisation, fp8 GEMMs (ov_gemm_fp8), bf16 attention, row re-quantisation in front of out_proj / c_proj.  Needs
  * width and mlp_pad % 128 == 0 and >= 384.  ov_tower_workspace_bytes grows accordingly: query it after setting the copies. */
 int       ov_tower_set_block_fp8(ov_tower* t, int layer, const ov_block_fp8* q);
-/* Static scale of the MLP hidden in the fp8 path.  h_amax: device float[layers] (borrowed).  mode 0: off (the hidden is written in
- * bf16 and re-quantised row by row); 1: same, and the running maximum of |hidden| per layer is recorded into h_amax (calibration);
- * 2: c_fc writes the hidden directly as e4m3 with the scale 2 * h_amax[layer] / 448 and c_proj reads it with that scale. */
-int       ov_tower_set_fp8_hidden_scale(ov_tower* t, float* h_amax, int mode);
+/* Static scales of the two re-quantised activations of the fp8 path.  amax: device float[2 * layers] (borrowed): [layer] = MLP
+ * hidden, [layers + layer] = attention output.  mode 0: off (both are written in bf16 and re-quantised row by row); 1: same, and
+ * their running maxima are recorded into amax (calibration); 2: the producers (c_fc epilogue, attention epilogue for head_dim 64)
+ * write e4m3 directly with the scale 2 * amax / 448 and the consumers (c_proj, out_proj) read it with that scalar scale. */
+int       ov_tower_set_fp8_hidden_scale(ov_tower* t, float* amax, int mode);
 size_t    ov_tower_workspace_bytes(const ov_tower* t, int B, int L);
 /* x[B*L, D] bf16 is updated in place through all `layers` blocks. */
 int       ov_tower_forward(const ov_tower* t, ov_bf16* x, int B, int L, void* workspace,

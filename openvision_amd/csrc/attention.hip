@@ -217,11 +217,20 @@ __device__ __forceinline__ bf16x8_t tr_join(u32x2_t a, u32x2_t b) {
     return __builtin_bit_cast(bf16x8_t, w);
 }
 
+// 4 floats -> 4 e4m3 bytes (saturating)
+__device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float d) {
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(a, -448.f, 448.f), __builtin_amdgcn_fmed3f(b, -448.f, 448.f), w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(c, -448.f, 448.f), __builtin_amdgcn_fmed3f(d, -448.f, 448.f), w, true);
+    return (unsigned)w;
+}
+
 struct AttnPArgs {
     const ov_bf16* qkv; int64_t ldq;
     ov_bf16* out; int64_t ldo;
     int L, H, nqt, KC, nheads;
     float scale_log2;
+    const float* out_amax;        // OUT8: the output is e4m3 bytes (ldo in bytes) with the static scale 2 * (*out_amax) / 448
 };
 
 __device__ __forceinline__ void stage_head(const AttnPArgs& a, int bh, char* slot, int wave, int lane, int nthreads) {
@@ -280,7 +289,8 @@ __device__ __forceinline__ u32x2_t tr_read_off(unsigned addr) {
 
 // DEEP = workgroups of <= 8 waves (2 per SIMD, 256 VGPRs each): both K tiles of the next step are fetched behind the S MFMAs
 // and all V fragments of a step are in flight from its start.
-template <bool DEEP>
+// OUT8: e4m3 output with a static scale (fp8 path: feeds the out-proj GEMM without a bf16 round trip); same 8 stores per head.
+template <bool DEEP, bool OUT8>
 __global__ __launch_bounds__(DEEP ? 512 : 640, DEEP ? 2 : 3) void attn_fwd_hd64_persist(const AttnPArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -292,6 +302,7 @@ __global__ __launch_bounds__(DEEP ? 512 : 640, DEEP ? 2 : 3) void attn_fwd_hd64_
     const int nk_tiles = (L + 31) >> 5;
     const int n = (a.nheads - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;     // heads of this workgroup
     if (n <= 0) return;
+    const float inv8 = OUT8 ? 448.0f / (2.0f * fmaxf(*a.out_amax, 1e-30f)) : 1.0f;
 
     const int k_lane = r * 128;
     const int k_sw = (r >> 1) & 7;
@@ -485,16 +496,28 @@ __global__ __launch_bounds__(DEEP ? 512 : 640, DEEP ? 2 : 3) void attn_fwd_hd64_
             const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lsum), __float_as_uint(lsum), false, false);
             l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
         }
-        const float inv = 1.0f / l;
-        ov_bf16* op = a.out + ((int64_t)(bh / a.H) * L + qrow) * a.ldo + (bh % a.H) * 64 + 4 * h2;
+        float inv = 1.0f / l;
+        if (OUT8) {
+            inv *= inv8;
+            unsigned char* op = (unsigned char*)a.out + ((int64_t)(bh / a.H) * L + qrow) * a.ldo + (bh % a.H) * 64 + 4 * h2;
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            const u32x2_t w0 = {pack_bf16x2(o0[4 * gq] * inv, o0[4 * gq + 1] * inv),
-                                pack_bf16x2(o0[4 * gq + 2] * inv, o0[4 * gq + 3] * inv)};
-            const u32x2_t w1 = {pack_bf16x2(o1[4 * gq] * inv, o1[4 * gq + 1] * inv),
-                                pack_bf16x2(o1[4 * gq + 2] * inv, o1[4 * gq + 3] * inv)};
-            asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(op + 8 * gq), "v"(w0) : "memory");
-            asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 0" :: "v"(op + 32 + 8 * gq), "v"(w1) : "memory");
+            for (int gq = 0; gq < 4; ++gq) {
+                const unsigned w0 = pack_fp8x4(o0[4 * gq] * inv, o0[4 * gq + 1] * inv, o0[4 * gq + 2] * inv, o0[4 * gq + 3] * inv);
+                const unsigned w1 = pack_fp8x4(o1[4 * gq] * inv, o1[4 * gq + 1] * inv, o1[4 * gq + 2] * inv, o1[4 * gq + 3] * inv);
+                asm volatile("global_store_dword %0, %1, off" :: "v"(op + 8 * gq), "v"(w0) : "memory");
+                asm volatile("global_store_dword %0, %1, off\n\ts_nop 0" :: "v"(op + 32 + 8 * gq), "v"(w1) : "memory");
+            }
+        } else {
+            ov_bf16* op = a.out + ((int64_t)(bh / a.H) * L + qrow) * a.ldo + (bh % a.H) * 64 + 4 * h2;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const u32x2_t w0 = {pack_bf16x2(o0[4 * gq] * inv, o0[4 * gq + 1] * inv),
+                                    pack_bf16x2(o0[4 * gq + 2] * inv, o0[4 * gq + 3] * inv)};
+                const u32x2_t w1 = {pack_bf16x2(o1[4 * gq] * inv, o1[4 * gq + 1] * inv),
+                                    pack_bf16x2(o1[4 * gq + 2] * inv, o1[4 * gq + 3] * inv)};
+                asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(op + 8 * gq), "v"(w0) : "memory");
+                asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 0" :: "v"(op + 32 + 8 * gq), "v"(w1) : "memory");
+            }
         }
         asm volatile("s_waitcnt vmcnt(8)" : "+v"(qn[0]), "+v"(qn[1]), "+v"(qn[2]), "+v"(qn[3]) :: "memory");
     }
@@ -513,8 +536,10 @@ struct AttnSArgs {
     ov_bf16* out; int64_t ldo;
     int L, H, nqt, nqb, nheads, nchunks;
     float scale_log2;
+    const float* out_amax;        // OUT8 (see AttnPArgs)
 };
 
+template <bool OUT8>
 __global__ __launch_bounds__(512, 4) void attn_fwd_hd64_stream(const AttnSArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -673,17 +698,27 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_hd64_stream(const AttnSArgs a
         const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lsum), __float_as_uint(lsum), false, false);
         l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
     }
-    const float inv = 1.0f / l;
+    float inv = 1.0f / l;
     if (qt * 32 + r < L) {
-        ov_bf16* op = a.out + ((int64_t)b * L + qrow) * a.ldo + h * 64 + 4 * h2;
+        if (OUT8) {
+            inv *= 448.0f / (2.0f * fmaxf(*a.out_amax, 1e-30f));
+            unsigned char* op = (unsigned char*)a.out + ((int64_t)b * L + qrow) * a.ldo + h * 64 + 4 * h2;
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            const u32x2_t w0 = {pack_bf16x2(o0[4 * gq] * inv, o0[4 * gq + 1] * inv),
-                                pack_bf16x2(o0[4 * gq + 2] * inv, o0[4 * gq + 3] * inv)};
-            const u32x2_t w1 = {pack_bf16x2(o1[4 * gq] * inv, o1[4 * gq + 1] * inv),
-                                pack_bf16x2(o1[4 * gq + 2] * inv, o1[4 * gq + 3] * inv)};
-            *(u32x2_t*)(op + 8 * gq) = w0;
-            *(u32x2_t*)(op + 32 + 8 * gq) = w1;
+            for (int gq = 0; gq < 4; ++gq) {
+                *(unsigned*)(op + 8 * gq) = pack_fp8x4(o0[4 * gq] * inv, o0[4 * gq + 1] * inv, o0[4 * gq + 2] * inv, o0[4 * gq + 3] * inv);
+                *(unsigned*)(op + 32 + 8 * gq) = pack_fp8x4(o1[4 * gq] * inv, o1[4 * gq + 1] * inv, o1[4 * gq + 2] * inv, o1[4 * gq + 3] * inv);
+            }
+        } else {
+            ov_bf16* op = a.out + ((int64_t)b * L + qrow) * a.ldo + h * 64 + 4 * h2;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const u32x2_t w0 = {pack_bf16x2(o0[4 * gq] * inv, o0[4 * gq + 1] * inv),
+                                    pack_bf16x2(o0[4 * gq + 2] * inv, o0[4 * gq + 3] * inv)};
+                const u32x2_t w1 = {pack_bf16x2(o1[4 * gq] * inv, o1[4 * gq + 1] * inv),
+                                    pack_bf16x2(o1[4 * gq + 2] * inv, o1[4 * gq + 3] * inv)};
+                *(u32x2_t*)(op + 8 * gq) = w0;
+                *(u32x2_t*)(op + 32 + 8 * gq) = w1;
+            }
         }
     }
 }
@@ -829,12 +864,33 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_generic(const AttnArgs a, int
 
 }  // namespace
 
+namespace {
+int attention_impl(const ov_bf16* qkv, int64_t ld_qkv, ov_bf16* out, int64_t ld_out, int B, int L, int H, int hd, float scale,
+                   const float* out_amax, ov_stream_t stream);
+}
+
 extern "C" int ov_attention(const ov_bf16* qkv, int64_t ld_qkv, ov_bf16* out, int64_t ld_out, int B, int L,
                             int H, int hd, float scale, ov_stream_t stream) {
+    return attention_impl(qkv, ld_qkv, out, ld_out, B, L, H, hd, scale, nullptr, stream);
+}
+
+// Same attention, output written as e4m3 bytes out8[B*L, H*64] (ld_out in bytes) with the static scale 2 * (*out_amax) / 448
+// (fp8 path: the out-proj GEMM reads it with that scalar scale).  head_dim 64 only; OV_ERR_UNSUPPORTED otherwise.
+extern "C" int ov_attention_fp8out(const ov_bf16* qkv, int64_t ld_qkv, unsigned char* out8, int64_t ld_out, int B, int L, int H,
+                                   int hd, float scale, const float* out_amax, ov_stream_t stream) {
+    if (!out_amax) return OV_ERR_INVALID;
+    if (hd != 64) return OV_ERR_UNSUPPORTED;
+    return attention_impl(qkv, ld_qkv, (ov_bf16*)out8, ld_out, B, L, H, hd, scale, out_amax, stream);
+}
+
+namespace {
+int attention_impl(const ov_bf16* qkv, int64_t ld_qkv, ov_bf16* out, int64_t ld_out, int B, int L, int H, int hd, float scale,
+                   const float* out_amax, ov_stream_t stream) {
     if (!qkv || !out || B <= 0 || L <= 0 || H <= 0) return OV_ERR_INVALID;
     if (hd <= 0 || hd % 8 || hd > 96) return OV_ERR_UNSUPPORTED;
     if (ld_qkv % 8 || ld_out % 8 || ld_qkv < 3 * H * hd || ld_out < H * hd) return OV_ERR_INVALID;
     if (((uintptr_t)qkv | (uintptr_t)out) & 15) return OV_ERR_INVALID;
+    const bool out8 = out_amax != nullptr;
     if (hd != 64) {                                      // So400m (72) / H (80): generic padded-head kernel
         AttnArgs g;
         g.qkv = qkv; g.ldq = ld_qkv; g.out = out; g.ldo = ld_out;
@@ -868,13 +924,17 @@ extern "C" int ov_attention(const ov_bf16* qkv, int64_t ld_qkv, ov_bf16* out, in
     if (lp <= 320 && !force_v1) {
         AttnPArgs p;
         p.qkv = qkv; p.ldq = ld_qkv; p.out = out; p.ldo = ld_out;
-        p.L = L; p.H = H; p.nqt = a.nqt; p.KC = lp; p.nheads = B * H; p.scale_log2 = a.scale_log2;
+        p.L = L; p.H = H; p.nqt = a.nqt; p.KC = lp; p.nheads = B * H; p.scale_log2 = a.scale_log2; p.out_amax = out_amax;
         static bool attr2 = false;
         if (!attr2) {
-            hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_hd64_persist<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+            hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_hd64_persist<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                160 * 1024);
             if (e == hipSuccess)
-                e = hipFuncSetAttribute((const void*)attn_fwd_hd64_persist<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                e = hipFuncSetAttribute((const void*)attn_fwd_hd64_persist<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute((const void*)attn_fwd_hd64_persist<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute((const void*)attn_fwd_hd64_persist<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return OV_ERR_HIP - (int)e;
             attr2 = true;
         }
@@ -892,10 +952,14 @@ extern "C" int ov_attention(const ov_bf16* qkv, int64_t ld_qkv, ov_bf16* out, in
         if (per_cu < 1) per_cu = 1;
         const int cap = ncu * per_cu;
         const int grid = p.nheads < cap ? p.nheads : cap;
-        if (a.nqt <= 8)
-            hipLaunchKernelGGL(attn_fwd_hd64_persist<true>, dim3((unsigned)grid), dim3(a.nqt * 64), smem, (hipStream_t)stream, p);
-        else
-            hipLaunchKernelGGL(attn_fwd_hd64_persist<false>, dim3((unsigned)grid), dim3(a.nqt * 64), smem, (hipStream_t)stream, p);
+        const dim3 pg((unsigned)grid), pb(a.nqt * 64);
+        if (a.nqt <= 8) {
+            if (out8) hipLaunchKernelGGL((attn_fwd_hd64_persist<true, true>), pg, pb, smem, (hipStream_t)stream, p);
+            else hipLaunchKernelGGL((attn_fwd_hd64_persist<true, false>), pg, pb, smem, (hipStream_t)stream, p);
+        } else {
+            if (out8) hipLaunchKernelGGL((attn_fwd_hd64_persist<false, true>), pg, pb, smem, (hipStream_t)stream, p);
+            else hipLaunchKernelGGL((attn_fwd_hd64_persist<false, false>), pg, pb, smem, (hipStream_t)stream, p);
+        }
         OV_LAUNCH_CHECK();
         return OV_OK;
     }
@@ -904,19 +968,24 @@ extern "C" int ov_attention(const ov_bf16* qkv, int64_t ld_qkv, ov_bf16* out, in
         sa.qkv = qkv; sa.ldq = ld_qkv; sa.out = out; sa.ldo = ld_out;
         sa.L = L; sa.H = H; sa.nqt = a.nqt; sa.nqb = (a.nqt + 7) / 8; sa.nheads = B * H; sa.nchunks = (L + 63) / 64;
         sa.scale_log2 = a.scale_log2;
+        sa.out_amax = out_amax;
         static bool attr4 = false;
         if (!attr4) {
-            hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_hd64_stream, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_hd64_stream<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute((const void*)attn_fwd_hd64_stream<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return OV_ERR_HIP - (int)e;
             attr4 = true;
         }
         const int64_t heads8 = ((int64_t)sa.nheads + 7) / 8 * 8;             // whole rounds of 8 XCDs; surplus ids exit at once
         const int64_t nwg = heads8 * sa.nqb;
         if (nwg > 0x7fffffffLL) return OV_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL(attn_fwd_hd64_stream, dim3((unsigned)nwg), dim3(512), 4 * 16384, (hipStream_t)stream, sa);
+        if (out8) hipLaunchKernelGGL(attn_fwd_hd64_stream<true>, dim3((unsigned)nwg), dim3(512), 4 * 16384, (hipStream_t)stream, sa);
+        else hipLaunchKernelGGL(attn_fwd_hd64_stream<false>, dim3((unsigned)nwg), dim3(512), 4 * 16384, (hipStream_t)stream, sa);
         OV_LAUNCH_CHECK();
         return OV_OK;
     }
+    if (out8) return OV_ERR_UNSUPPORTED;                // the fallback kernel has no e4m3 epilogue
     int nw;
     if (lp <= 320) { a.KC = lp; nw = a.nqt; }          // whole K/V of a head resident: one chunk
     else { a.KC = 256; nw = 8; }
@@ -934,3 +1003,4 @@ extern "C" int ov_attention(const ov_bf16* qkv, int64_t ld_qkv, ov_bf16* out, in
     OV_LAUNCH_CHECK();
     return OV_OK;
 }
+}  // namespace

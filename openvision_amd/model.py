@@ -357,9 +357,9 @@ class _TowerHandle:
         self.width, self.layers, self.fp8 = d, len(blocks), fp8
         self.h_amax = None
         if fp8:
-            # per-layer running maximum of the MLP hidden: recorded while the hidden is quantised row by row (mode 1), then the
-            # static scale of the fused c_fc -> c_proj hand-over (mode 2, freeze_fp8_scales)
-            self.h_amax = torch.zeros(len(blocks), dtype=torch.float32, device=b0.attn.in_proj_weight.device)
+            # per-layer running maxima of the MLP hidden and of the attention output: recorded while they are quantised row by row
+            # (mode 1), then the static scales of the fused c_fc -> c_proj and attention -> out_proj hand-overs (mode 2)
+            self.h_amax = torch.zeros(2 * len(blocks), dtype=torch.float32, device=b0.attn.in_proj_weight.device)   # hidden | attention out
             check(lib.ov_tower_set_fp8_hidden_scale(self.handle, ptr(self.h_amax), 1), "ov_tower_set_fp8_hidden_scale")
 
     def freeze_fp8_scales(self) -> None:

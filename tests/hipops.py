@@ -113,3 +113,12 @@ def gemm_fp8_static(aq, wq, colscale, bias, epi, rowscale=None, in_amax=None, ou
                                  ptr(out), out.stride(0), ptr(out_amax) if out_amax is not None else None, m, n, k, epi,
                                  ptr(resid) if resid is not None else None, resid.stride(0) if resid is not None else 0, stream_ptr()))
     return out
+
+
+def attention_fp8out(qkv, B, L, Hh, amax):
+    """head_dim 64; returns e4m3 bytes [B*L, Hh*64] under the static scale 2 * amax / 448."""
+    lib = _lib.load()
+    d = Hh * 64
+    out = torch.empty(B * L, d, dtype=torch.uint8, device=qkv.device)
+    check(lib.ov_attention_fp8out(ptr(qkv), qkv.stride(0), ptr(out), out.stride(0), B, L, Hh, 64, 0.125, ptr(amax), stream_ptr()))
+    return out

@@ -258,3 +258,17 @@ def test_gemm_fp8_static_scales():
     out = H.gemm_fp8_static(h8, w2q, c2, b2.to(DEV), 3, in_amax=amax, resid=res.to(DEV)).float()
     ref = hq @ deq(w2q, c2).T + b2.to(DEV) + res.to(DEV).float()
     np.testing.assert_allclose(out.cpu().numpy(), ref.cpu().numpy(), rtol=1e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("B,L,H_", [(2, 257, 4), (3, 128, 2), (1, 577, 3), (2, 2305, 1)])
+def test_attention_fp8_output(B, L, H_):
+    """e4m3 epilogue of the persistent (9-wave and <= 8-wave) and streaming attention kernels: equal to quantising the bf16 kernel's
+    own fp32 result with the static scale, up to the bf16 rounding that the bf16 path adds and the e4m3 step."""
+    D = H_ * 64
+    qkv = rnd(B * L, 3 * D, seed=70).to(torch.bfloat16).to(DEV)
+    ref = H.attention(qkv, B, L, H_).float()
+    amax = ref.abs().max().reshape(1).contiguous()
+    o8 = H.attention_fp8out(qkv, B, L, H_, amax)
+    sc = 2.0 * amax / 448.0
+    deq = o8.view(torch.float8_e4m3fn).float() * sc
+    assert ((deq - ref).abs() <= ref.abs() * 0.075 + sc * 2.0 ** -9 * 1.01 + 1e-6).all()
