@@ -54,7 +54,10 @@ template <int V> struct IntC { static constexpr int value = V; };
 // HEADROOM * amax_out / 448 (feeds the next fp8 GEMM without a bf16 round trip).  MODE 2: one static input scale, bf16 output.
 template <int EPI, int MODE>
 __device__ __forceinline__ void epilogue_fp8(const Fp8Args& g, f32x4_t (&acc)[8][4], char* img, const char* prm, int64_t m0, int n0,
-                                             int wave, int lane, bool edge, float rs_const, float inv_out) {
+                                             int wave, int lane_in, bool edge, float rs_const, float inv_out) {
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));       // opaque: the epilogue's per-lane addresses are recomputed per tile, not carried (and spilled)
+                                         // through the main loop as loop invariants
     const int wm = wave >> 2, wn = wave & 3;
     const int fr = lane & 15, fq = lane >> 4;
     const int er = lane >> 3, ec = lane & 7;
