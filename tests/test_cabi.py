@@ -50,3 +50,33 @@ def test_argument_validation_without_gpu():
     lib.ov_tower_destroy(t)
     bad = _lib.TowerCfg(100, 2, 3, 400, 400, 0, 1e-6)        # width not a multiple of 64
     assert lib.ov_tower_create(ctypes.byref(bad)) is None
+
+
+def test_argument_validation_of_the_widening_entry_points():
+    """Entry points added for the §8f rows and the fp8 path: invalid arguments are status codes, never HIP calls or crashes."""
+    lib = _lib.load()
+    assert lib.ov_gemm_fp8(None, 1024, None, 1024, None, None, None, None, 1024, 256, 256, 1024, 0, None, 0, None) == -1
+    assert lib.ov_gemm_fp8_static(None, 1024, None, 1024, None, None, None, None, None, 1024, None, 256, 256, 1024, 1, None, 0, None) == -1
+    assert lib.ov_quant_rows_fp8(None, 1024, None, 1024, None, 4, 1024, None, None) == -1
+    assert lib.ov_layernorm_quant_fp8(None, 1024, None, None, None, 1024, None, 4, 1024, 1e-6, None) == -1
+    assert lib.ov_attention_fp8out(None, 192, None, 64, 1, 32, 1, 64, 0.125, None, None) == -1
+    assert lib.ov_topk(None, 8, 1, 8, 1, 1, None, None, None) == -1
+    assert lib.ov_class_mean_normalize(None, None, 1, 1, 8, None) == -1
+    assert lib.ov_preprocess_image(None, 8, 8, None, None, 1, 8, None, None, 1, 8, 0, 8, None, 0, 0, 8, 8, None, None, None, 0, None) == -1
+    # fp8 copies need K-tiles of 128 elements, at least three of them: a 192-wide tower is refused, a 384-wide one accepted
+    small = _lib.TowerCfg(192, 1, 3, 768, 768, 0, 1e-6)
+    t = lib.ov_tower_create(ctypes.byref(small))
+    dummy = (ctypes.c_char * 64)()
+    addr = (ctypes.addressof(dummy) + 15) & ~15
+    q = _lib.BlockFp8(*([addr] * 10))
+    assert lib.ov_tower_set_block_fp8(t, 0, ctypes.byref(q)) == -2
+    assert lib.ov_tower_set_fp8_hidden_scale(t, None, 1) == -1
+    lib.ov_tower_destroy(t)
+    ok = _lib.TowerCfg(384, 1, 6, 1536, 1536, 0, 1e-6)
+    t = lib.ov_tower_create(ctypes.byref(ok))
+    base = lib.ov_tower_workspace_bytes(t, 2, 64)
+    assert lib.ov_tower_set_block_fp8(t, 0, ctypes.byref(q)) == 0
+    assert lib.ov_tower_workspace_bytes(t, 2, 64) > base            # room for the e4m3 activations and their scales
+    assert lib.ov_tower_set_block_fp8(t, 0, None) == 0              # cleared: back to the bf16 footprint
+    assert lib.ov_tower_workspace_bytes(t, 2, 64) == base
+    lib.ov_tower_destroy(t)
