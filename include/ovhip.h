@@ -141,7 +141,7 @@ int ov_logits(const float* X, const float* Y, float* out, int64_t ldo, int n1, i
 /* ov_attention with the output written as e4m3 bytes out8[B*L, H*64] (ld_out in bytes) under the static scale 2 * (*out_amax) / 448
  * (device scalar; fp8 path: the out-proj GEMM then reads it through ov_gemm_fp8_static).  head_dim 64; else OV_ERR_UNSUPPORTED. */
 int ov_attention_fp8out(const ov_bf16* qkv, int64_t ld_qkv, unsigned char* out8, int64_t ld_out, int B, int L, int H, int hd,
-                        float scale, const float* out_amax, ov_stream_t stream);
+                        float scale, const float* out_amax, float* out_amax_next /* optional running maximum */, ov_stream_t stream);
 
 /* ---- fp8 GEMM (BASELINE.json config #5: fp8 weights/activations on the CDNA4 fp8 MFMA) --------------------------------------
  * C = epilogue(rowscale[m] * colscale[n] * (A . W^T) + bias):  A [M, K], W [N, K] OCP e4m3fn bytes (K contiguous, lda/ldw in
@@ -159,7 +159,10 @@ int ov_gemm_fp8(const unsigned char* A, int64_t lda, const unsigned char* W, int
  * Exactly one of the two is set. */
 int ov_gemm_fp8_static(const unsigned char* A, int64_t lda, const unsigned char* W, int64_t ldw, const float* rowscale,
                        const float* in_amax, const float* colscale, const float* bias, void* C, int64_t ldc, const float* out_amax,
-                       int64_t M, int N, int K, int epilogue, const ov_bf16* R, int64_t ldr, ov_stream_t stream);
+                       float* out_amax_next /* optional: running maximum of |C| for the next call */, int64_t M, int N, int K,
+                       int epilogue, const ov_bf16* R, int64_t ldr, ov_stream_t stream);
+/* cur[i] = max(cur[i], next[i]), i < n (delayed scaling: roll the recorded maxima into the scales at the top of a forward). */
+int ov_amax_roll(float* cur, const float* next, int n, ov_stream_t stream);
 
 /* Activation quantisation for ov_gemm_fp8: q[r,:] = e4m3(y[r,:] / s_r), s_r = max|y[r,:]| / 448, with y = x (ov_quant_rows_fp8) or
  * y = LayerNorm(x) * gamma + beta in fp32 (ov_layernorm_quant_fp8; eps, biased variance as transformer.py:15-30).  x bf16
@@ -261,8 +264,9 @@ int       ov_tower_set_block(ov_tower* t, int layer, const ov_block_weights* w);
  * with row quantisation, fp8 GEMMs (ov_gemm_fp8), bf16 attention, row re-quantisation in front of out_proj / c_proj.  Needs
  * width and mlp_pad % 128 == 0 and >= 384.  ov_tower_workspace_bytes grows accordingly: query it after setting the copies. */
 int       ov_tower_set_block_fp8(ov_tower* t, int layer, const ov_block_fp8* q);
-/* Static scales of the two re-quantised activations of the fp8 path.  amax: device float[2 * layers] (borrowed): [layer] = MLP
- * hidden, [layers + layer] = attention output.  mode 0: off (both are written in bf16 and re-quantised row by row); 1: same, and
+/* Static (delayed) scales of the two re-quantised activations of the fp8 path.  amax: device float[4 * layers] (borrowed):
+ * [layer] = MLP hidden, [layers + layer] = attention output, [2 * layers ...) = the same two sets as recorded during the
+ * running forward (rolled into the first half at the top of the next one).  mode 0: off (both are written in bf16 and re-quantised row by row); 1: same, and
  * their running maxima are recorded into amax (calibration); 2: the producers (c_fc epilogue, attention epilogue for head_dim 64)
  * write e4m3 directly with the scale 2 * amax / 448 and the consumers (c_proj, out_proj) read it with that scalar scale. */
 int       ov_tower_set_fp8_hidden_scale(ov_tower* t, float* amax, int mode);

@@ -57,9 +57,10 @@ SIGNATURES = {
     "ov_gemm_fp8": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int,
                             c_int, c_void_p, c_int64, c_void_p]),
     "ov_quant_rows_fp8": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
-    "ov_attention_fp8out": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "ov_attention_fp8out": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "ov_amax_roll": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "ov_gemm_fp8_static": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
-                                   c_int64, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
+                                   c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
     "ov_tower_set_fp8_hidden_scale": (c_int, [c_void_p, c_void_p, c_int]),
     "ov_layernorm_quant_fp8": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_float,
                                        c_void_p]),

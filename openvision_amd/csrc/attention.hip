@@ -231,6 +231,7 @@ struct AttnPArgs {
     int L, H, nqt, KC, nheads;
     float scale_log2;
     const float* out_amax;        // OUT8: the output is e4m3 bytes (ldo in bytes) with the static scale 2 * (*out_amax) / 448
+    float* amax_next;             // OUT8, optional: running maximum of |output| (the next call's scale)
 };
 
 __device__ __forceinline__ void stage_head(const AttnPArgs& a, int bh, char* slot, int wave, int lane, int nthreads) {
@@ -303,6 +304,7 @@ __global__ __launch_bounds__(DEEP ? 512 : 640, DEEP ? 2 : 3) void attn_fwd_hd64_
     const int n = (a.nheads - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;     // heads of this workgroup
     if (n <= 0) return;
     const float inv8 = OUT8 ? 448.0f / (2.0f * fmaxf(*a.out_amax, 1e-30f)) : 1.0f;
+    const float next_thr = (OUT8 && a.amax_next != nullptr) ? *a.amax_next : 0.f;   // read once: no global load inside the head loop
 
     const int k_lane = r * 128;
     const int k_sw = (r >> 1) & 7;
@@ -498,6 +500,15 @@ __global__ __launch_bounds__(DEEP ? 512 : 640, DEEP ? 2 : 3) void attn_fwd_hd64_
         }
         float inv = 1.0f / l;
         if (OUT8) {
+            if (a.amax_next != nullptr) {          // delayed scaling; the (rare) atomic is issued AHEAD of the 8 stores the vmcnt(8) below counts
+                float lm = 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) lm = fmaxf(lm, fmaxf(fabsf(o0[i]), fabsf(o1[i])));
+                lm *= inv;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) lm = fmaxf(lm, __shfl_xor(lm, o, 64));
+                if (lane == 0 && lm > next_thr) atomicMax((unsigned*)a.amax_next, __float_as_uint(lm));
+            }
             inv *= inv8;
             unsigned char* op = (unsigned char*)a.out + ((int64_t)(bh / a.H) * L + qrow) * a.ldo + (bh % a.H) * 64 + 4 * h2;
 #pragma unroll
@@ -537,6 +548,7 @@ struct AttnSArgs {
     int L, H, nqt, nqb, nheads, nchunks;
     float scale_log2;
     const float* out_amax;        // OUT8 (see AttnPArgs)
+    float* amax_next;
 };
 
 template <bool OUT8>
@@ -699,6 +711,15 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_hd64_stream(const AttnSArgs a
         l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
     }
     float inv = 1.0f / l;
+    if (OUT8 && a.amax_next != nullptr) {                         // delayed scaling: running maximum of |output| (all lanes take part)
+        float lm = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) lm = fmaxf(lm, fmaxf(fabsf(o0[i]), fabsf(o1[i])));
+        lm = qt * 32 + r < L ? lm * inv : 0.f;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) lm = fmaxf(lm, __shfl_xor(lm, o, 64));
+        if (lane == 0 && lm > *(volatile float*)a.amax_next) atomicMax((unsigned*)a.amax_next, __float_as_uint(lm));
+    }
     if (qt * 32 + r < L) {
         if (OUT8) {
             inv *= 448.0f / (2.0f * fmaxf(*a.out_amax, 1e-30f));
@@ -866,26 +887,26 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_generic(const AttnArgs a, int
 
 namespace {
 int attention_impl(const ov_bf16* qkv, int64_t ld_qkv, ov_bf16* out, int64_t ld_out, int B, int L, int H, int hd, float scale,
-                   const float* out_amax, ov_stream_t stream);
+                   const float* out_amax, float* amax_next, ov_stream_t stream);
 }
 
 extern "C" int ov_attention(const ov_bf16* qkv, int64_t ld_qkv, ov_bf16* out, int64_t ld_out, int B, int L,
                             int H, int hd, float scale, ov_stream_t stream) {
-    return attention_impl(qkv, ld_qkv, out, ld_out, B, L, H, hd, scale, nullptr, stream);
+    return attention_impl(qkv, ld_qkv, out, ld_out, B, L, H, hd, scale, nullptr, nullptr, stream);
 }
 
 // Same attention, output written as e4m3 bytes out8[B*L, H*64] (ld_out in bytes) with the static scale 2 * (*out_amax) / 448
 // (fp8 path: the out-proj GEMM reads it with that scalar scale).  head_dim 64 only; OV_ERR_UNSUPPORTED otherwise.
 extern "C" int ov_attention_fp8out(const ov_bf16* qkv, int64_t ld_qkv, unsigned char* out8, int64_t ld_out, int B, int L, int H,
-                                   int hd, float scale, const float* out_amax, ov_stream_t stream) {
+                                   int hd, float scale, const float* out_amax, float* out_amax_next, ov_stream_t stream) {
     if (!out_amax) return OV_ERR_INVALID;
     if (hd != 64) return OV_ERR_UNSUPPORTED;
-    return attention_impl(qkv, ld_qkv, (ov_bf16*)out8, ld_out, B, L, H, hd, scale, out_amax, stream);
+    return attention_impl(qkv, ld_qkv, (ov_bf16*)out8, ld_out, B, L, H, hd, scale, out_amax, out_amax_next, stream);
 }
 
 namespace {
 int attention_impl(const ov_bf16* qkv, int64_t ld_qkv, ov_bf16* out, int64_t ld_out, int B, int L, int H, int hd, float scale,
-                   const float* out_amax, ov_stream_t stream) {
+                   const float* out_amax, float* amax_next, ov_stream_t stream) {
     if (!qkv || !out || B <= 0 || L <= 0 || H <= 0) return OV_ERR_INVALID;
     if (hd <= 0 || hd % 8 || hd > 96) return OV_ERR_UNSUPPORTED;
     if (ld_qkv % 8 || ld_out % 8 || ld_qkv < 3 * H * hd || ld_out < H * hd) return OV_ERR_INVALID;
@@ -924,7 +945,7 @@ int attention_impl(const ov_bf16* qkv, int64_t ld_qkv, ov_bf16* out, int64_t ld_
     if (lp <= 320 && !force_v1) {
         AttnPArgs p;
         p.qkv = qkv; p.ldq = ld_qkv; p.out = out; p.ldo = ld_out;
-        p.L = L; p.H = H; p.nqt = a.nqt; p.KC = lp; p.nheads = B * H; p.scale_log2 = a.scale_log2; p.out_amax = out_amax;
+        p.L = L; p.H = H; p.nqt = a.nqt; p.KC = lp; p.nheads = B * H; p.scale_log2 = a.scale_log2; p.out_amax = out_amax; p.amax_next = amax_next;
         static bool attr2 = false;
         if (!attr2) {
             hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_hd64_persist<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -969,6 +990,7 @@ int attention_impl(const ov_bf16* qkv, int64_t ld_qkv, ov_bf16* out, int64_t ld_
         sa.L = L; sa.H = H; sa.nqt = a.nqt; sa.nqb = (a.nqt + 7) / 8; sa.nheads = B * H; sa.nchunks = (L + 63) / 64;
         sa.scale_log2 = a.scale_log2;
         sa.out_amax = out_amax;
+        sa.amax_next = amax_next;
         static bool attr4 = false;
         if (!attr4) {
             hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_hd64_stream<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

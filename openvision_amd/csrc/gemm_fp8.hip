@@ -43,6 +43,7 @@ struct Fp8Args {
     int N, K, tiles_m, tiles_n;
     const float* amax_in;      // MODE 2: every row of A was quantised with the scale HEADROOM * (*amax_in) / 448 (rowscale unused)
     const float* amax_out;     // MODE 1: C is written as e4m3 bytes with that static scale of its own
+    float* amax_next;          // MODE 1, optional: running maximum of |C| before quantisation (the NEXT call's scale: delayed scaling)
 };
 
 constexpr float HEADROOM = 2.0f;   // static activation scales leave one binade above the calibrated maximum (e4m3 is floating point:
@@ -54,7 +55,7 @@ template <int V> struct IntC { static constexpr int value = V; };
 // HEADROOM * amax_out / 448 (feeds the next fp8 GEMM without a bf16 round trip).  MODE 2: one static input scale, bf16 output.
 template <int EPI, int MODE>
 __device__ __forceinline__ void epilogue_fp8(const Fp8Args& g, f32x4_t (&acc)[8][4], char* img, const char* prm, int64_t m0, int n0,
-                                             int wave, int lane_in, bool edge, float rs_const, float inv_out) {
+                                             int wave, int lane_in, bool edge, float rs_const, float inv_out, float next_thr) {
     int lane = lane_in;
     asm volatile("" : "+v"(lane));       // opaque: the epilogue's per-lane addresses are recomputed per tile, not carried (and spilled)
                                          // through the main loop as loop invariants
@@ -100,6 +101,7 @@ __device__ __forceinline__ void epilogue_fp8(const Fp8Args& g, f32x4_t (&acc)[8]
     const int wsw = fr & 7;
     const char* const rd = img + er * 128 + ((ec ^ er) << 4);
     u32x4_t vo[8][2];
+    float lmax = 0.f;
     auto put = [&](int i) {
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
@@ -135,6 +137,8 @@ __device__ __forceinline__ void epilogue_fp8(const Fp8Args& g, f32x4_t (&acc)[8]
                 if (EPI == OV_EPI_BIAS_GELU_TANH) { v01 = gelu_tanh_f2(v01); v23 = gelu_tanh_f2(v23); }
                 if (MODE == 1) {
                     // 4 consecutive n -> 4 e4m3 bytes; image rows are 64 B (16 dwords), chunk ^= (row >> 1) & 3
+                    lmax = fmaxf(fmaxf(lmax, fabsf(v01[0])), fabsf(v01[1]));     // two v_max3_f32 with |x| source modifiers
+                    lmax = fmaxf(fmaxf(lmax, fabsf(v23[0])), fabsf(v23[1]));
                     const f32x2_t io = {inv_out, inv_out};
                     v01 *= io; v23 *= io;
                     int pk8 = 0;
@@ -167,6 +171,12 @@ __device__ __forceinline__ void epilogue_fp8(const Fp8Args& g, f32x4_t (&acc)[8]
                 vo[i][1] = *(const u32x4_t*)(rd + 1024);
             }
         }
+    }
+    if (MODE == 1 && g.amax_next != nullptr) {       // delayed scaling: this tile's maximum feeds the next call's scale
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o, 64));
+        // next_thr = the value at kernel start: a load here would make the compiler wait for this epilogue's stores to be acknowledged
+        if (lane == 0 && lmax > next_thr) atomicMax((unsigned*)g.amax_next, __float_as_uint(lmax));
     }
 }
 
@@ -255,6 +265,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_fp8_persist(const Fp8Args g)
 
     const float rs_const = MODE == 2 ? HEADROOM * (1.0f / 448.0f) * *g.amax_in : 0.f;
     const float inv_out = MODE == 1 ? 448.0f / (HEADROOM * fmaxf(*g.amax_out, 1e-30f)) : 0.f;
+    const float next_thr = (MODE == 1 && g.amax_next != nullptr) ? *g.amax_next : 0.f;
     const int wm = wave >> 2, wn = wave & 3;
     const int fr = lane & 15, fq = lane >> 4;
     // fragment reads: operand row `row` of a piece, logical chunks 2 fq and 2 fq + 1 -> physical chunk ^ (row & 7) = ^ (fr & 7)
@@ -368,7 +379,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_fp8_persist(const Fp8Args g)
         __builtin_amdgcn_sched_barrier(0);
         const bool edge = (m0 + BM > g.M) || (n0 + BN > g.N);
         epilogue_fp8<EPI, MODE>(g, acc, smem + IMG_OFF + wave * 2048, smem + PRM_OFF + pslot * 4096, m0, n0, wave, lane, edge, rs_const,
-                                inv_out);
+                                inv_out, next_thr);
         if (!has_next) break;
         strict = edge;
         __builtin_amdgcn_sched_barrier(0);
@@ -423,7 +434,7 @@ extern "C" int ov_gemm_fp8(const unsigned char* A, int64_t lda, const unsigned c
     if (bias && ((uintptr_t)bias & 15)) return OV_ERR_INVALID;
     if (epilogue == OV_EPI_BIAS_RESIDUAL && (!R || ldr % 8 || ldr < N || ((uintptr_t)R & 15))) return OV_ERR_INVALID;
     const Fp8Args a{A, W, bias, rowscale, colscale, C, R, lda, ldw, ldc, ldr, M, N, K, (int)((M + BM - 1) / BM), (int)((N + BN - 1) / BN),
-                    nullptr, nullptr};
+                    nullptr, nullptr, nullptr};
     hipStream_t st = (hipStream_t)stream;
     switch (epilogue) {
         case OV_EPI_BIAS: return launch_fp8<OV_EPI_BIAS, 0>(a, st);
@@ -437,17 +448,18 @@ extern "C" int ov_gemm_fp8(const unsigned char* A, int64_t lda, const unsigned c
 // The same GEMM with a STATIC scale on one side (calibrated activation maximum, device scalar; scale = 2 * amax / 448):
 //   out_amax != NULL: C is written as e4m3 bytes C8[M, N] (ldc in bytes, % 16, N % 16 == 0) quantised with out_amax's scale
 //                     -- epilogue OV_EPI_BIAS_GELU_ERF / _TANH (the c_fc -> c_proj hand-over without a bf16 round trip);
+//                     out_amax_next (optional): running maximum of |C| before quantisation, for the next call (delayed scaling);
 //   in_amax  != NULL: every row of A carries in_amax's scale (rowscale ignored) -- epilogue OV_EPI_BIAS_RESIDUAL.
 extern "C" int ov_gemm_fp8_static(const unsigned char* A, int64_t lda, const unsigned char* W, int64_t ldw, const float* rowscale,
                                   const float* in_amax, const float* colscale, const float* bias, void* C, int64_t ldc,
-                                  const float* out_amax, int64_t M, int N, int K, int epilogue, const ov_bf16* R, int64_t ldr,
-                                  ov_stream_t stream) {
+                                  const float* out_amax, float* out_amax_next, int64_t M, int N, int K, int epilogue,
+                                  const ov_bf16* R, int64_t ldr, ov_stream_t stream) {
     int rc = check_fp8(A, lda, W, ldw, C, ldc, M, N, K);
     if (rc) return rc;
     if (!colscale || ((uintptr_t)colscale & 15) || (bias && ((uintptr_t)bias & 15))) return OV_ERR_INVALID;
     if ((in_amax != nullptr) == (out_amax != nullptr)) return OV_ERR_INVALID;          // exactly one static side
     const Fp8Args a{A, W, bias, rowscale, colscale, (ov_bf16*)C, R, lda, ldw, ldc, ldr, M, N, K, (int)((M + BM - 1) / BM),
-                    (int)((N + BN - 1) / BN), in_amax, out_amax};
+                    (int)((N + BN - 1) / BN), in_amax, out_amax, out_amax_next};
     hipStream_t st = (hipStream_t)stream;
     if (out_amax) {
         if (!rowscale || N % 16 || ldc % 16) return OV_ERR_INVALID;

@@ -100,6 +100,11 @@ __global__ __launch_bounds__(256) void quant_rows(const ov_bf16* __restrict__ x,
     }
 }
 
+__global__ void amax_roll_kernel(float* cur, const float* next, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) cur[i] = fmaxf(cur[i], next[i]);
+}
+
 template <bool LN>
 int launch_quant(const ov_bf16* x, int64_t ldx, const float* g, const float* b, unsigned char* q, int64_t ldq, float* scale,
                  int64_t rows, int D, float eps, float* amax_acc, hipStream_t st) {
@@ -135,4 +140,13 @@ extern "C" int ov_layernorm_quant_fp8(const ov_bf16* x, int64_t ldx, const float
     if (D % 8 || D > 8192 || ldx % 8 || ldx < D || ldq % 8 || ldq < D) return OV_ERR_UNSUPPORTED;
     if (((uintptr_t)x & 15) || ((uintptr_t)q & 7) || (((uintptr_t)gamma | (uintptr_t)beta) & 15)) return OV_ERR_INVALID;
     return launch_quant<true>(x, ldx, gamma, beta, q, ldq, rowscale, rows, D, eps, nullptr, (hipStream_t)stream);
+}
+
+// Delayed scaling: cur[i] = max(cur[i], next[i]) -- the maxima recorded by the producers of the previous forward become the scales of
+// this one (launched once at the top of a forward, so every kernel of a forward sees one consistent value).
+extern "C" int ov_amax_roll(float* cur, const float* next, int n, ov_stream_t stream) {
+    if (!cur || !next || n <= 0) return OV_ERR_INVALID;
+    hipLaunchKernelGGL(amax_roll_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, cur, next, n);
+    OV_LAUNCH_CHECK();
+    return OV_OK;
 }

@@ -22,7 +22,7 @@ struct ov_tower {
     unsigned char* set;
     ov_block_fp8* fp8;            // optional fp8 copies (config #5); the fp8 path runs when every layer has one
     unsigned char* set8;
-    float* h_amax;                // fp8 path: [2 * layers] maxima of the MLP hidden and of the attention output (device, borrowed)
+    float* h_amax;                // fp8 path: [4 * layers]: scales' maxima (hidden | attention out) and the running ones (device, borrowed)
     int h_mode;
 };
 
@@ -318,7 +318,8 @@ namespace {
 // The same block with fp8 (e4m3) GEMM operands (BASELINE.json config #5): LN -> row quantisation fused, attention in bf16,
 // the attention output and the MLP hidden re-quantised row by row in front of out-proj / c_proj.
 int run_block_fp8(const ov_tower_cfg& c, const ov_block_weights& w, const ov_block_fp8& q, ov_bf16* x, ov_bf16* h, ov_bf16* big,
-                  unsigned char* q8, float* qs, float* h_amax, float* a_amax, int h_mode, int B, int L, ov_stream_t stream, bool prof) {
+                  unsigned char* q8, float* qs, float* h_amax, float* a_amax, float* h_next, float* a_next, int h_mode, int B, int L,
+                  ov_stream_t stream, bool prof) {
     const int D = c.width, H = c.heads, hd = D / H, F = c.mlp_pad;
     const int64_t M = (int64_t)B * L;
     const int ldb = 3 * D > F ? 3 * D : F;
@@ -336,8 +337,8 @@ int run_block_fp8(const ov_tower_cfg& c, const ov_block_weights& w, const ov_blo
     OV_STEP(OV_PROF_GEMM_QKV, ov_gemm_fp8(q8, D, q.qkv_w8, D, qs, q.qkv_s, q.qkv_b, big, ldb, M, 3 * D, D, OV_EPI_BIAS, nullptr, 0, stream));
     if (h_mode == 2 && hd == 64) {
         // static scale: the attention epilogue writes e4m3 itself (into the fp8 activation buffer, free at this point)
-        OV_STEP(OV_PROF_ATTN, ov_attention_fp8out(big, ldb, q8, D, B, L, H, hd, scale, a_amax, stream));
-        OV_STEP(OV_PROF_GEMM_OUT, ov_gemm_fp8_static(q8, D, q.out_w8, D, nullptr, a_amax, q.out_s, w.out_b, x, D, nullptr, M, D, D,
+        OV_STEP(OV_PROF_ATTN, ov_attention_fp8out(big, ldb, q8, D, B, L, H, hd, scale, a_amax, a_next, stream));
+        OV_STEP(OV_PROF_GEMM_OUT, ov_gemm_fp8_static(q8, D, q.out_w8, D, nullptr, a_amax, q.out_s, w.out_b, x, D, nullptr, nullptr, M, D, D,
                                                      OV_EPI_BIAS_RESIDUAL, x, D, stream));
     } else {
         OV_STEP(OV_PROF_ATTN, ov_attention(big, ldb, h, D, B, L, H, hd, scale, stream));
@@ -348,8 +349,8 @@ int run_block_fp8(const ov_tower_cfg& c, const ov_block_weights& w, const ov_blo
     if (h_mode == 2) {
         // static hidden scale: c_fc quantises its own output (e4m3 bytes, pitch F, in the `big` region), c_proj reads it as is
         unsigned char* h8 = (unsigned char*)big;
-        OV_STEP(fc_cls, ov_gemm_fp8_static(q8, D, q.fc_w8, D, qs, nullptr, q.fc_s, q.fc_b, h8, F, h_amax, M, F, D, gelu, nullptr, 0, stream));
-        OV_STEP(OV_PROF_GEMM_PROJ, ov_gemm_fp8_static(h8, F, q.proj_w8, F, nullptr, h_amax, q.proj_s, w.proj_b, x, D, nullptr, M, D, F,
+        OV_STEP(fc_cls, ov_gemm_fp8_static(q8, D, q.fc_w8, D, qs, nullptr, q.fc_s, q.fc_b, h8, F, h_amax, h_next, M, F, D, gelu, nullptr, 0, stream));
+        OV_STEP(OV_PROF_GEMM_PROJ, ov_gemm_fp8_static(h8, F, q.proj_w8, F, nullptr, h_amax, q.proj_s, w.proj_b, x, D, nullptr, nullptr, M, D, F,
                                                       OV_EPI_BIAS_RESIDUAL, x, D, stream));
     } else {
         OV_STEP(fc_cls, ov_gemm_fp8(q8, D, q.fc_w8, D, qs, q.fc_s, q.fc_b, big, ldb, M, F, D, gelu, nullptr, 0, stream));
@@ -393,19 +394,25 @@ extern "C" int ov_tower_forward(const ov_tower* t, ov_bf16* x, int B, int L, voi
     }
     const int64_t off = (int64_t)Bm * L;
     const bool fp8 = tower_fp8(t);
+    if (fp8 && t->h_amax && t->h_mode == 2) {          // delayed scaling: last forward's maxima become this forward's scales
+        int rc = ov_amax_roll(t->h_amax, t->h_amax + 2 * c.layers, 2 * c.layers, stream);
+        if (rc) return rc;
+    }
     const int qw = D > c.mlp_pad ? D : c.mlp_pad;                 // row pitch reserved per token in the fp8 activation buffer
     unsigned char* q8 = (unsigned char*)stats + align_up((size_t)M * 8, 256);
     float* qs = (float*)(q8 + align_up((size_t)M * qw, 256));
     for (int i = 0; i < c.layers; ++i) {
         float* ha = t->h_amax ? t->h_amax + i : nullptr;
         float* aa = t->h_amax ? t->h_amax + c.layers + i : nullptr;
+        float* hn = t->h_amax ? t->h_amax + 2 * c.layers + i : nullptr;
+        float* an = t->h_amax ? t->h_amax + 3 * c.layers + i : nullptr;
         const int hm = t->h_amax ? t->h_mode : 0;
-        int rc = fp8 ? run_block_fp8(c, t->blocks[i], t->fp8[i], x, h, big, q8, qs, ha, aa, hm, Bm, L, stream, true)
+        int rc = fp8 ? run_block_fp8(c, t->blocks[i], t->fp8[i], x, h, big, q8, qs, ha, aa, hn, an, hm, Bm, L, stream, true)
                      : run_block(c, t->blocks[i], x, h, big, stats, Bm, L, stream, true);
         if (rc) return rc;
         if (nt > 0) {
             rc = fp8 ? run_block_fp8(c, t->blocks[i], t->fp8[i], x + off * D, h + off * D, big + off * ldb, q8 + off * qw, qs + off,
-                                     ha, aa, hm, nt, L, (ov_stream_t)tc->stream, false)
+                                     ha, aa, hn, an, hm, nt, L, (ov_stream_t)tc->stream, false)
                      : run_block(c, t->blocks[i], x + off * D, h + off * D, big + off * ldb, stats + 2 * off, nt, L,
                                  (ov_stream_t)tc->stream, false);
             if (rc) return rc;

@@ -359,13 +359,14 @@ class _TowerHandle:
         if fp8:
             # per-layer running maxima of the MLP hidden and of the attention output: recorded while they are quantised row by row
             # (mode 1), then the static scales of the fused c_fc -> c_proj and attention -> out_proj hand-overs (mode 2)
-            self.h_amax = torch.zeros(2 * len(blocks), dtype=torch.float32, device=b0.attn.in_proj_weight.device)   # hidden | attention out
+            # [hidden | attention out] maxima behind the scales, then the same two sets as recorded by the running forward
+            self.h_amax = torch.zeros(4 * len(blocks), dtype=torch.float32, device=b0.attn.in_proj_weight.device)
             check(lib.ov_tower_set_fp8_hidden_scale(self.handle, ptr(self.h_amax), 1), "ov_tower_set_fp8_hidden_scale")
 
     def freeze_fp8_scales(self) -> None:
         if not self.fp8:
             raise _lib.OvhipError("freeze_fp8_scales: the tower is not in fp8 precision")
-        if not bool((self.h_amax > 0).all()):
+        if not bool((self.h_amax[: 2 * self.layers] > 0).all()):
             raise _lib.OvhipError("freeze_fp8_scales: run at least one forward in fp8 precision first (calibration)")
         check(_lib.load().ov_tower_set_fp8_hidden_scale(self.handle, ptr(self.h_amax), 2), "ov_tower_set_fp8_hidden_scale")
 

@@ -102,7 +102,7 @@ def quant_rows_fp8(x, gamma=None, beta=None, eps=1e-6, amax=None):
     return q, sc
 
 
-def gemm_fp8_static(aq, wq, colscale, bias, epi, rowscale=None, in_amax=None, out_amax=None, resid=None):
+def gemm_fp8_static(aq, wq, colscale, bias, epi, rowscale=None, in_amax=None, out_amax=None, resid=None, amax_next=None):
     """out_amax: returns e4m3 bytes [m, n]; in_amax: returns bf16."""
     lib = _lib.load()
     m, k = aq.shape
@@ -110,15 +110,17 @@ def gemm_fp8_static(aq, wq, colscale, bias, epi, rowscale=None, in_amax=None, ou
     out = torch.empty(m, n, dtype=torch.uint8 if out_amax is not None else torch.bfloat16, device=aq.device)
     check(lib.ov_gemm_fp8_static(ptr(aq), aq.stride(0), ptr(wq), wq.stride(0), ptr(rowscale) if rowscale is not None else None,
                                  ptr(in_amax) if in_amax is not None else None, ptr(colscale), ptr(bias) if bias is not None else None,
-                                 ptr(out), out.stride(0), ptr(out_amax) if out_amax is not None else None, m, n, k, epi,
+                                 ptr(out), out.stride(0), ptr(out_amax) if out_amax is not None else None,
+                                 ptr(amax_next) if amax_next is not None else None, m, n, k, epi,
                                  ptr(resid) if resid is not None else None, resid.stride(0) if resid is not None else 0, stream_ptr()))
     return out
 
 
-def attention_fp8out(qkv, B, L, Hh, amax):
+def attention_fp8out(qkv, B, L, Hh, amax, amax_next=None):
     """head_dim 64; returns e4m3 bytes [B*L, Hh*64] under the static scale 2 * amax / 448."""
     lib = _lib.load()
     d = Hh * 64
     out = torch.empty(B * L, d, dtype=torch.uint8, device=qkv.device)
-    check(lib.ov_attention_fp8out(ptr(qkv), qkv.stride(0), ptr(out), out.stride(0), B, L, Hh, 64, 0.125, ptr(amax), stream_ptr()))
+    check(lib.ov_attention_fp8out(ptr(qkv), qkv.stride(0), ptr(out), out.stride(0), B, L, Hh, 64, 0.125, ptr(amax),
+                                  ptr(amax_next) if amax_next is not None else None, stream_ptr()))
     return out

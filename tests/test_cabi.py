@@ -56,10 +56,11 @@ def test_argument_validation_of_the_widening_entry_points():
     """Entry points added for the §8f rows and the fp8 path: invalid arguments are status codes, never HIP calls or crashes."""
     lib = _lib.load()
     assert lib.ov_gemm_fp8(None, 1024, None, 1024, None, None, None, None, 1024, 256, 256, 1024, 0, None, 0, None) == -1
-    assert lib.ov_gemm_fp8_static(None, 1024, None, 1024, None, None, None, None, None, 1024, None, 256, 256, 1024, 1, None, 0, None) == -1
+    assert lib.ov_gemm_fp8_static(None, 1024, None, 1024, None, None, None, None, None, 1024, None, None, 256, 256, 1024, 1, None, 0, None) == -1
+    assert lib.ov_amax_roll(None, None, 4, None) == -1
     assert lib.ov_quant_rows_fp8(None, 1024, None, 1024, None, 4, 1024, None, None) == -1
     assert lib.ov_layernorm_quant_fp8(None, 1024, None, None, None, 1024, None, 4, 1024, 1e-6, None) == -1
-    assert lib.ov_attention_fp8out(None, 192, None, 64, 1, 32, 1, 64, 0.125, None, None) == -1
+    assert lib.ov_attention_fp8out(None, 192, None, 64, 1, 32, 1, 64, 0.125, None, None, None) == -1
     assert lib.ov_topk(None, 8, 1, 8, 1, 1, None, None, None) == -1
     assert lib.ov_class_mean_normalize(None, None, 1, 1, 8, None) == -1
     assert lib.ov_preprocess_image(None, 8, 8, None, None, 1, 8, None, None, 1, 8, 0, 8, None, 0, 0, 8, 8, None, None, None, 0, None) == -1

@@ -291,6 +291,14 @@ def test_fp8_precision_large14():
         m.encode_image(img); m.encode_text(tok)                           # calibration pass of the re-packed towers
         m.freeze_fp8_scales()
         f8s, t8s = m.encode_image(img, normalize=True), m.encode_text(tok, normalize=True)
+        # delayed scaling: the producers keep recording maxima, the next forward rolls them into the scales
+        tw = m.visual.transformer.tower()
+        nl = tw.layers
+        cur0 = tw.h_amax[: 2 * nl].clone()
+        assert bool((tw.h_amax[2 * nl:] > 0).all())
+        m.encode_image(img * 3.0)                                          # larger activations ...
+        m.encode_image(img)                                                # ... are rolled in at the top of the following forward
+        assert bool((tw.h_amax[: 2 * nl] >= cur0).all()) and bool((tw.h_amax[: 2 * nl] > cur0).any())
     finally:
         m.set_precision("bf16")
     cis = torch.nn.functional.cosine_similarity(f8s.cpu(), ref_i).min().item()

@@ -246,7 +246,9 @@ def test_gemm_fp8_static_scales():
     deq = lambda q, s_: q.view(torch.float8_e4m3fn).float() * s_[:, None]
     hid = torch.nn.functional.gelu(deq(aq, rs) @ deq(w1q, c1).T + b1.to(DEV))
     amax = hid.abs().max().reshape(1).contiguous()
-    h8 = H.gemm_fp8_static(aq, w1q, c1, b1.to(DEV), 1, rowscale=rs, out_amax=amax)
+    nxt = torch.zeros(1, device=DEV)
+    h8 = H.gemm_fp8_static(aq, w1q, c1, b1.to(DEV), 1, rowscale=rs, out_amax=amax, amax_next=nxt)
+    assert abs(nxt.item() - amax.item()) <= 1e-3 * amax.item() + 1e-3          # delayed scaling: the running maximum of |C|
     sc = 2.0 * amax / 448.0
     hq = h8.view(torch.float8_e4m3fn).float() * sc
     assert (hq - hid).abs().max() <= hid.abs().max() * 0.07 + 1e-3              # e4m3 step relative to the element's own magnitude
@@ -268,7 +270,9 @@ def test_attention_fp8_output(B, L, H_):
     qkv = rnd(B * L, 3 * D, seed=70).to(torch.bfloat16).to(DEV)
     ref = H.attention(qkv, B, L, H_).float()
     amax = ref.abs().max().reshape(1).contiguous()
-    o8 = H.attention_fp8out(qkv, B, L, H_, amax)
+    nxt = torch.zeros(1, device=DEV)
+    o8 = H.attention_fp8out(qkv, B, L, H_, amax, nxt)
+    assert abs(nxt.item() - amax.item()) <= 0.01 * amax.item()                 # running maximum (ref is the bf16-rounded output)
     sc = 2.0 * amax / 448.0
     deq = o8.view(torch.float8_e4m3fn).float() * sc
     assert ((deq - ref).abs() <= ref.abs() * 0.075 + sc * 2.0 ** -9 * 1.01 + 1e-6).all()
