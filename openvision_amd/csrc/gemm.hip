@@ -766,7 +766,11 @@ int launch(GemmArgs a, hipStream_t st) {
     int var = gemm_variant();
     const int nwg = a.tiles_m * a.tiles_n;
     // fewer tiles than CUs (pooled heads, the tower's tail images): persistence buys nothing, use the plain launch
-    if (var == 0 && (nwg < num_cus() || a.K < 3 * BK)) var = 2;
+    // the persistent kernel also wins on grids somewhat smaller than the chip (one tile per workgroup, but its epilogue starts
+    // without global round trips); tiny grids (the tower's tail images) stay on the plain launch
+    static int min_persist = -1;
+    if (min_persist < 0) { const char* e = getenv("OVHIP_GEMM_MINPERSIST"); min_persist = e ? atoi(e) : num_cus(); }
+    if (var == 0 && (nwg < min_persist || a.K < 3 * BK)) var = 2;
     if (var == 1) {
         hipLaunchKernelGGL(gemm_bf16_256x256<EPI>, dim3(nwg), dim3(NTHREADS), 0, st, a);
     } else if (var == 2) {
