@@ -237,24 +237,28 @@ struct AttnPArgs {
 __device__ __forceinline__ void stage_head(const AttnPArgs& a, int bh, char* slot, int wave, int lane, int nthreads) {
     const int b = bh / a.H, h = bh - b * a.H;
     const int HD = a.H * 64, KC = a.KC, L = a.L;
-    const ov_bf16* base = a.qkv + (int64_t)b * L * a.ldq + h * 64;
+    // wave-uniform base + 32-bit per-lane byte offsets (L * ldq * 2 < 4 GiB: checked by the launcher): the DMA issue is on every
+    // head's critical path, 64-bit per-piece address arithmetic made it ~300 cycles per 1-KiB piece
+    const char* base = (const char*)(a.qkv + (int64_t)b * L * a.ldq + h * 64);
+    const unsigned rowb = (unsigned)(a.ldq * 2);
+    const unsigned last = (unsigned)(L - 1) * rowb;
     char* ks = slot;
     char* vs = slot + KC * 128;
     const int nchunk = KC * 8;
-    for (int q0c = wave * 64; q0c < nchunk; q0c += nthreads) {
-        const int q = q0c + lane;
+    // K piece q = q0c + lane: key q >> 3, source d-chunk (q & 7) ^ ((key >> 1) & 7).  V piece: d-half dh = (q0c >= 4 KC), key
+    // (q - dh 4 KC) >> 2, d-chunk dh * 4 + (q & 3).  q0c is a multiple of 64, so q & 7 = lane & 7 and q & 3 = lane & 3.
+    for (int q0c = wave * 64; q0c < nchunk; q0c += nthreads) {   // nothing per-lane is carried between trips (register room)
         {
-            const int key = q >> 3;
-            const int row = key < L ? key : L - 1;
-            const int c = (q & 7) ^ ((key >> 1) & 7);
-            __builtin_amdgcn_global_load_lds((gptr_t)(base + (int64_t)row * a.ldq + HD + c * 8), (lptr_t)(ks + q0c * 16), 16, 0, 0);
+            const int kkey = (q0c + lane) >> 3;
+            const unsigned ro = kkey < L ? (unsigned)kkey * rowb : last;
+            const int c = (lane & 7) ^ ((kkey >> 1) & 7);
+            __builtin_amdgcn_global_load_lds((gptr_t)(base + (ro + (unsigned)((HD + c * 8) * 2))), (lptr_t)(ks + q0c * 16), 16, 0, 0);
         }
         {
-            const int dh = q0c >= KC * 4 ? 1 : 0;
-            const int qq = q - dh * KC * 4;
-            const int key = qq >> 2;
-            const int row = key < L ? key : L - 1;
-            __builtin_amdgcn_global_load_lds((gptr_t)(base + (int64_t)row * a.ldq + 2 * HD + (dh * 4 + (qq & 3)) * 8),
+            const int dh = q0c >= KC * 4 ? 1 : 0;                 // wave-uniform
+            const int vkey = (q0c - dh * KC * 4 + lane) >> 2;
+            const unsigned ro = vkey < L ? (unsigned)vkey * rowb : last;
+            __builtin_amdgcn_global_load_lds((gptr_t)(base + (ro + (unsigned)((2 * HD + (dh * 4 + (lane & 3)) * 8) * 2))),
                                              (lptr_t)(vs + q0c * 16), 16, 0, 0);
         }
     }
@@ -942,7 +946,7 @@ int attention_impl(const ov_bf16* qkv, int64_t ld_qkv, ov_bf16* out, int64_t ld_
     const int lp = a.nqt * 32;
     static int force_v1 = -1;
     if (force_v1 < 0) { const char* e = getenv("OVHIP_ATTN_V1"); force_v1 = (e && e[0] == '1') ? 1 : 0; }
-    if (lp <= 320 && !force_v1) {
+    if (lp <= 320 && !force_v1 && (int64_t)L * ld_qkv * 2 < 0x7fffffffLL) {
         AttnPArgs p;
         p.qkv = qkv; p.ldq = ld_qkv; p.out = out; p.ldo = ld_out;
         p.L = L; p.H = H; p.nqt = a.nqt; p.KC = lp; p.nheads = B * H; p.scale_log2 = a.scale_log2; p.out_amax = out_amax; p.amax_next = amax_next;
