@@ -232,6 +232,7 @@ struct AttnPArgs {
     float scale_log2;
     const float* out_amax;        // OUT8: the output is e4m3 bytes (ldo in bytes) with the static scale 2 * (*out_amax) / 448
     float* amax_next;             // OUT8, optional: running maximum of |output| (the next call's scale)
+    int lone_valu;                // 1: a single-key last tile is folded in on the VALU (OVHIP_ATTN_LONEKEY=0 keeps the tile step)
 };
 
 __device__ __forceinline__ void stage_head(const AttnPArgs& a, int bh, char* slot, int wave, int lane, int nthreads) {
@@ -305,6 +306,8 @@ __global__ __launch_bounds__(DEEP ? 512 : 640, DEEP ? 2 : 3) void attn_fwd_hd64_
     const int L = a.L, KC = a.KC;
     const int slot_bytes = KC * 256;
     const int nk_tiles = (L + 31) >> 5;
+    const bool lone_on = a.lone_valu != 0;
+    const bool lone_key = lone_on && (L & 31) == 1 && (nk_tiles & 1) && nk_tiles > 1;   // an odd last key tile that holds a single key
     const int n = (a.nheads - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;     // heads of this workgroup
     if (n <= 0) return;
     const float inv8 = OUT8 ? 448.0f / (2.0f * fmaxf(*a.out_amax, 1e-30f)) : 1.0f;
@@ -458,7 +461,63 @@ __global__ __launch_bounds__(DEEP ? 512 : 640, DEEP ? 2 : 3) void attn_fwd_hd64_
             o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join(vu[6], vu[7]), pb1, o1, 0, 0, 0);
         }
         if (j + 1 < n) load_q(qn, bh + gridDim.x);                   // next head's Q rows, live only across the tail step
-        if (nk_tiles & 1) {
+        if (lone_key) {
+            // L = 32 k + 1 (ViT: patches + cls): the odd last key tile holds ONE key.  A tile step for it is a full dependent
+            // chain (LDS -> 4 MFMAs -> softmax on 32 columns -> 4 MFMAs, ~2.3 k cycles per head and wave); the same update on the
+            // VALU: the staged rows past L-1 are copies of row L-1, so this lane's own K fragments of the tile ARE that key
+            // (its d range), 16 v_dot2 give q.k, then one exp2 and 32 FMAs with the key's V row.
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const u32x4_t kq = __builtin_bit_cast(u32x4_t, kfa[st]), qq = __builtin_bit_cast(u32x4_t, qf[st]);
+                // inline asm: hipcc's lowering of the fdot2 builtin on dwords extracted from the fragments picked dword 0 of every
+                // fragment for all four products (checked in the ISA)
+                asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(s0) : "v"(qq[0]), "v"(kq[0]));
+                asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(s1) : "v"(qq[1]), "v"(kq[1]));
+                asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(s0) : "v"(qq[2]), "v"(kq[2]));
+                asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(s1) : "v"(qq[3]), "v"(kq[3]));
+            }
+            asm("s_nop 2" : "+v"(s0), "+v"(s1));                      // DOT result -> ordinary VALU read: 3 wait states the assembler
+                                                                      // does not insert inside inline asm
+            float sd = s0 + s1;                                       // this lane's half of d; the other half sits in lane ^ 32
+            {
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(sd), __float_as_uint(sd), false, false);
+                sd = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+            }
+            // the key's V row: d = 8 g + 4 h2 + e (o0), + 32 (o1): four 8-byte reads per d-half of the V image
+            const char* vrow = ks + KC * 128 + (L - 1) * 64 + 8 * h2;
+            u32x2_t v0[4];                                            // d-half 0 now, d-half 1 into the same registers afterwards
+#pragma unroll
+            for (int g = 0; g < 4; ++g) v0[g] = *(const u32x2_t*)(vrow + g * 16);
+            const float mx = sd * a.scale_log2;
+            if (!__all(mx - m <= 8.0f)) {
+                const float mn = fmaxf(m, mx);
+                const float alpha = __builtin_amdgcn_exp2f(m - mn);
+                m = mn;
+                lsum *= alpha;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+            }
+            const float pk = __builtin_amdgcn_exp2f(mx - m);
+            lsum += h2 ? 0.f : pk;                                    // the halves' sums are added at the end: count the key once
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                o0[4 * g + 0] = fmaf(pk, bf16lo_to_f32(v0[g][0]), o0[4 * g + 0]);
+                o0[4 * g + 1] = fmaf(pk, bf16hi_to_f32(v0[g][0]), o0[4 * g + 1]);
+                o0[4 * g + 2] = fmaf(pk, bf16lo_to_f32(v0[g][1]), o0[4 * g + 2]);
+                o0[4 * g + 3] = fmaf(pk, bf16hi_to_f32(v0[g][1]), o0[4 * g + 3]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) v0[g] = *(const u32x2_t*)(vrow + KC * 64 + g * 16);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                o1[4 * g + 0] = fmaf(pk, bf16lo_to_f32(v0[g][0]), o1[4 * g + 0]);
+                o1[4 * g + 1] = fmaf(pk, bf16hi_to_f32(v0[g][0]), o1[4 * g + 1]);
+                o1[4 * g + 2] = fmaf(pk, bf16lo_to_f32(v0[g][1]), o1[4 * g + 2]);
+                o1[4 * g + 3] = fmaf(pk, bf16hi_to_f32(v0[g][1]), o1[4 * g + 3]);
+            }
+        } else if (nk_tiles & 1) {
             const int kt = nk_tiles - 1;
             const unsigned va0 = ks_u + kt * 2048 + v_lane0, va1 = ks_u + kt * 2048 + v_lane1;
             u32x2_t vt[8];
@@ -950,6 +1009,7 @@ int attention_impl(const ov_bf16* qkv, int64_t ld_qkv, ov_bf16* out, int64_t ld_
         AttnPArgs p;
         p.qkv = qkv; p.ldq = ld_qkv; p.out = out; p.ldo = ld_out;
         p.L = L; p.H = H; p.nqt = a.nqt; p.KC = lp; p.nheads = B * H; p.scale_log2 = a.scale_log2; p.out_amax = out_amax; p.amax_next = amax_next;
+        { static int lk = -1; if (lk < 0) { const char* e = getenv("OVHIP_ATTN_LONEKEY"); lk = (e && e[0] == '0') ? 0 : 1; } p.lone_valu = lk; }
         static bool attr2 = false;
         if (!attr2) {
             hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_hd64_persist<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
