@@ -206,6 +206,19 @@ int ov_clip_loss(const float* img, const float* txt, const float* all_img, const
                  int b, int N, int E, float logit_scale, int label_offset, float* loss_out,
                  float* lse_out, void* workspace, size_t workspace_bytes, ov_stream_t stream);
 
+/* Backward of ov_clip_loss (loss.py:102-131 differentiated; the reference gets it from autograd): with P = softmax - onehot of
+ * each [b, N] strip (recomputed, never materialised; lse_terms = the [4, b] block ov_clip_loss wrote) and c = grad_loss *
+ * logit_scale / (2 b):   d_img = c P_i all_txt,  d_txt = c P_t all_img            (local rows, [b, E], always written)
+ *                        d_all_txt = c P_i^T img, d_all_img = c P_t^T txt          (gathered rows, [N, E]; NULL = skip)
+ *                        d_scale = grad_loss / (2 b) * sum P .* (x . y)            (device scalar; NULL = skip)
+ * The caller routes the gathered-side terms (gather_features, loss.py:19-63: own chunk only, or reduce-scatter when
+ * gather_with_grad).  E % 32 == 0, E <= 1152; OV_ERR_UNSUPPORTED otherwise.  Deterministic (no atomics). */
+size_t ov_clip_loss_backward_workspace_bytes(int b, int N);
+int ov_clip_loss_backward(const float* img, const float* txt, const float* all_img, const float* all_txt, int b, int N, int E,
+                          float logit_scale, int label_offset, const float* lse_terms, float grad_loss, float* d_img,
+                          float* d_txt, float* d_all_img, float* d_all_txt, float* d_scale, void* workspace,
+                          size_t workspace_bytes, ov_stream_t stream);
+
 /* ---- in-situ kernel timing (used by bench.py for the roofline object; off by default) ------------------
  * ov_profile_enable(mask, n): bracket every launch of the selected classes inside ov_tower_forward with a pair
  * of HIP events recorded on the launch stream (n = max launches recorded; resets earlier records; mask 0 = off).

@@ -84,6 +84,9 @@ SIGNATURES = {
     "ov_clip_loss_workspace_bytes": (c_size_t, [c_int, c_int]),
     "ov_clip_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p,
                              c_void_p, c_void_p, c_size_t, c_void_p]),
+    "ov_clip_loss_backward_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "ov_clip_loss_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p,
+                                      c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "ov_profile_enable": (c_int, [C.c_uint, c_int]),
     "ov_profile_read": (c_int, [c_int, C.POINTER(C.c_double), C.POINTER(c_int), C.POINTER(C.c_double)]),
     "ov_debug_gemm_stamps": (c_int, [c_void_p, c_int]),

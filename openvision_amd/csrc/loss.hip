@@ -157,6 +157,129 @@ __global__ __launch_bounds__(64) void logits_kernel(const float* __restrict__ X,
     }
 }
 
+
+// ---- backward of the InfoNCE strips (first piece of the training path: loss.py:102-131 differentiated) -----------------------
+// d loss / d logits = (softmax - onehot) / (2 b) per direction; the logit tiles are recomputed with the same exact-fp32 MFMA
+// (never materialised), P = exp(s * S - lse[row]) - [label] is formed in registers from the forward's per-row LSE, and the
+// product P . X_in accumulates into [32 rows x E] fp32 MFMA accumulators split over the four waves of a workgroup by 32-column
+// e-tile.  The S tile's K reduction is split the same way (each wave contracts its own e-tiles) and summed through LDS.
+//   MODE_B = false: out rows = LOCAL rows (lse by out row):     d x_local[r]  = c * sum_g P[r, g] * y_all[g]
+//   MODE_B = true : out rows = GATHERED rows (lse by in row):   d y_all[g]    = c * sum_r P[r, g] * x_local[r]
+// One workgroup per (32-row tile, direction); the in-side loop is not split, so the result is deterministic (no atomics).
+constexpr int BWD_MAXT = 9;          // e-tiles per wave: E <= 4 * 9 * 32 = 1152
+
+struct LossBwdArgs {
+    const float* xo[2];     // out-side rows [no, E]
+    const float* xi[2];     // in-side rows  [ni, E]
+    const float* lse[2];    // per LOCAL row
+    float* out[2];          // [no, E]
+    float* dsc_part;        // [2][nrt]  (MODE_B = false only)
+    int no, ni, E, label_offset, nrt;
+    float scale, coef;
+};
+
+template <bool MODE_B>
+__global__ __launch_bounds__(256) void clip_loss_bwd(const LossBwdArgs a) {
+    __shared__ float part[4][16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, half = lane >> 5;
+    const int rt = blockIdx.x, dir = blockIdx.y;
+    const float* __restrict__ XO = a.xo[dir];
+    const float* __restrict__ XI = a.xi[dir];
+    const float* __restrict__ LSE = a.lse[dir];
+    float* __restrict__ OUT = a.out[dir];
+    if (OUT == nullptr) return;                                   // direction not requested (workgroup-uniform)
+    const int E = a.E, net = E >> 5;
+    const int nown = (net - wave + 3) >> 2;                       // e-tiles wave, wave + 4, ...
+    const int o = rt * 32 + j;
+    const int oc = o < a.no ? o : a.no - 1;
+    const float* xop = XO + (int64_t)oc * E + 4 * half;
+    const float lse_o = MODE_B ? 0.f : LSE[oc];
+
+    f32x16_t acc_o[BWD_MAXT];
+#pragma unroll
+    for (int n = 0; n < BWD_MAXT; ++n)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc_o[n][i] = 0.f;
+    float dsc = 0.f;
+
+    const int ntiles = (a.ni + 31) >> 5;
+    for (int t = 0; t < ntiles; ++t) {
+        int gi = t * 32 + j;
+        gi = gi < a.ni ? gi : a.ni - 1;
+        const float* yip = XI + (int64_t)gi * E + 4 * half;
+        f32x16_t acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        for (int n = 0; n < nown; ++n) {
+            const int e0 = (wave + 4 * n) * 32;
+#pragma unroll
+            for (int k0 = 0; k0 < 32; k0 += 8) {
+                const float4 av = *(const float4*)(yip + e0 + k0);
+                const float4 bv = *(const float4*)(xop + e0 + k0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+            }
+        }
+        __syncthreads();                                          // the previous tile's partials have been consumed
+#pragma unroll
+        for (int i = 0; i < 16; ++i) part[wave][i][lane] = acc[i];
+        __syncthreads();
+        // acc[i] = <XI[t*32 + (i&3) + 8*(i>>2) + 4*half], XO[o]>, summed over the waves in a fixed order
+        f32x16_t p;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float sdot = ((part[0][i][lane] + part[1][i][lane]) + part[2][i][lane]) + part[3][i][lane];
+            const int g = t * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
+            const bool valid = o < a.no && g < a.ni;
+            const float lse_v = MODE_B ? LSE[g < a.ni ? g : a.ni - 1] : lse_o;
+            const bool hit = MODE_B ? (o == g + a.label_offset) : (g == o + a.label_offset);
+            const float pv = valid ? __expf(sdot * a.scale - lse_v) - (hit ? 1.f : 0.f) : 0.f;
+            p[i] = pv;
+            dsc = fmaf(pv, sdot, dsc);
+        }
+        // out[o, e] += sum_g P[o, g] * XI[g, e]: contraction step s pairs g0(s) = (s&3) + 8*(s>>2) (k = 0, held by the lower lane
+        // half as register s) with g0(s) + 4 (k = 1, upper half): the A operand is this lane's own p[s]
+#pragma unroll
+        for (int n = 0; n < BWD_MAXT; ++n) {
+            if (n < nown) {
+                const int e = (wave + 4 * n) * 32 + j;
+#pragma unroll
+                for (int s2 = 0; s2 < 16; ++s2) {
+                    int g = t * 32 + (s2 & 3) + 8 * (s2 >> 2) + 4 * half;
+                    g = g < a.ni ? g : a.ni - 1;
+                    const float yv = XI[(int64_t)g * E + e];
+                    acc_o[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(p[s2], yv, acc_o[n], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < BWD_MAXT; ++n) {
+        if (n < nown) {
+            const int e = (wave + 4 * n) * 32 + j;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = rt * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
+                if (row < a.no) OUT[(int64_t)row * E + e] = acc_o[n][i] * a.coef;
+            }
+        }
+    }
+    if (!MODE_B) {                                                // d loss / d scale: every wave holds the same P; wave 0 reports
+        dsc = wave_sum(dsc);
+        if (wave == 0 && lane == 0) a.dsc_part[dir * a.nrt + rt] = dsc;
+    }
+}
+
+__global__ __launch_bounds__(64) void clip_loss_bwd_scale(const float* __restrict__ part, int n, float coef, float* __restrict__ d_scale) {
+    float v = 0.f;
+    for (int i = threadIdx.x; i < n; i += 64) v += part[i];
+    v = wave_sum(v);
+    if (threadIdx.x == 0) d_scale[0] = v * coef;
+}
+
 struct Plan { int bpad, nrt, ntiles, nsplit, tps; };
 
 inline Plan make_plan(int b, int N) {
@@ -204,6 +327,48 @@ extern "C" int ov_clip_loss(const float* img, const float* txt, const float* all
     OV_LAUNCH_CHECK();
     hipLaunchKernelGGL(clip_loss_finalize, dim3(1), dim3(256), 0, st, a.part, a.diag, b, p.bpad, p.nsplit, loss_out, lse_out);
     OV_LAUNCH_CHECK();
+    return OV_OK;
+}
+
+
+extern "C" size_t ov_clip_loss_backward_workspace_bytes(int b, int N) {
+    if (b <= 0 || N <= 0) return 0;
+    return (size_t)2 * ((b + 31) / 32) * sizeof(float) + 64;
+}
+
+extern "C" int ov_clip_loss_backward(const float* img, const float* txt, const float* all_img, const float* all_txt, int b, int N,
+                                     int E, float logit_scale, int label_offset, const float* lse_terms, float grad_loss,
+                                     float* d_img, float* d_txt, float* d_all_img, float* d_all_txt, float* d_scale,
+                                     void* workspace, size_t workspace_bytes, ov_stream_t stream) {
+    if (!img || !txt || !all_img || !all_txt || !lse_terms || !d_img || !d_txt || !workspace) return OV_ERR_INVALID;
+    if (b <= 0 || N < b || E <= 0 || label_offset < 0 || label_offset + b > N) return OV_ERR_INVALID;
+    if (E % 32 || E > 4 * BWD_MAXT * 32) return OV_ERR_UNSUPPORTED;
+    if (((uintptr_t)img | (uintptr_t)txt | (uintptr_t)all_img | (uintptr_t)all_txt | (uintptr_t)workspace) & 15) return OV_ERR_INVALID;
+    if (workspace_bytes < ov_clip_loss_backward_workspace_bytes(b, N)) return OV_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const float inv2b = grad_loss / (2.0f * (float)b);
+    LossBwdArgs a;
+    a.E = E; a.label_offset = label_offset; a.scale = logit_scale; a.coef = inv2b * logit_scale;
+    a.lse[0] = lse_terms; a.lse[1] = lse_terms + (size_t)2 * b;
+    a.dsc_part = (float*)workspace;
+    // local side: d img = c * P_i . all_txt, d txt = c * P_t . all_img
+    a.xo[0] = img; a.xi[0] = all_txt; a.out[0] = d_img;
+    a.xo[1] = txt; a.xi[1] = all_img; a.out[1] = d_txt;
+    a.no = b; a.ni = N; a.nrt = (b + 31) / 32;
+    hipLaunchKernelGGL(clip_loss_bwd<false>, dim3((unsigned)a.nrt, 2), dim3(256), 0, st, a);
+    OV_LAUNCH_CHECK();
+    if (d_scale) {
+        hipLaunchKernelGGL(clip_loss_bwd_scale, dim3(1), dim3(64), 0, st, a.dsc_part, 2 * a.nrt, inv2b, d_scale);
+        OV_LAUNCH_CHECK();
+    }
+    if (d_all_img || d_all_txt) {
+        // gathered side: d all_txt = c * P_i^T . img (direction 0), d all_img = c * P_t^T . txt (direction 1)
+        a.xo[0] = all_txt; a.xi[0] = img; a.out[0] = d_all_txt;
+        a.xo[1] = all_img; a.xi[1] = txt; a.out[1] = d_all_img;
+        a.no = N; a.ni = b; a.nrt = (N + 31) / 32;
+        hipLaunchKernelGGL(clip_loss_bwd<true>, dim3((unsigned)a.nrt, 2), dim3(256), 0, st, a);
+        OV_LAUNCH_CHECK();
+    }
     return OV_OK;
 }
 

@@ -5,7 +5,10 @@ the packed ``[b, 2E]`` buffer (``torch.distributed`` backend "nccl" == RCCL over
 sets (loss.py:52-61), then the fused HIP kernel computes the local ``[b, N]`` logit strips both ways with labels
 ``i + b*rank`` (loss.py:93-94,108-110) without materialising them.
 
-Forward only: ``gather_with_grad`` is accepted for signature compatibility but no gradient flows.
+Gradients: when a feature tensor or ``logit_scale`` requires grad, the loss is an autograd node whose backward is the
+HIP kernel behind ``ov_clip_loss_backward`` (d loss / d features and d loss / d logit_scale; the towers themselves are
+forward-only in this build, so this is where a training step's backward starts).  The gathered-side terms are routed as
+``gather_features`` does (loss.py:19-63): own chunk only, or summed over ranks (reduce-scatter) with ``gather_with_grad``.
 ``use_horovod`` is rejected (RCCL via torch.distributed is the only transport here).
 """
 from __future__ import annotations
@@ -70,6 +73,13 @@ class ClipLoss(nn.Module):
         return out[0]
 
     def forward(self, image_features, text_features, logit_scale, output_dict: bool = False):
+        needs_grad = torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad
+                                                     for t in (image_features, text_features, logit_scale))
+        if needs_grad:
+            if not isinstance(logit_scale, torch.Tensor):
+                logit_scale = torch.tensor(float(logit_scale), device=image_features.device)
+            loss = _ClipLossFn.apply(self, image_features, text_features, logit_scale)
+            return {"contrastive_loss": loss} if output_dict else loss
         scale = float(logit_scale.detach()) if isinstance(logit_scale, torch.Tensor) else float(logit_scale)
         if self.world_size > 1:
             all_img, all_txt = gather_features(image_features, text_features, self.local_loss, self.gather_with_grad,
@@ -82,3 +92,74 @@ class ClipLoss(nn.Module):
         else:
             loss = self._loss_strips(image_features, text_features, image_features, text_features, scale, 0)
         return {"contrastive_loss": loss} if output_dict else loss
+
+
+def _sum_over_ranks_own_chunk(full: torch.Tensor, b: int, rank: int, group=None) -> torch.Tensor:
+    """Backward of ``torch.distributed.nn.all_gather`` (loss.py:49-50): every rank's [N, 2E] gathered-side gradient summed,
+    this rank keeps rows [rank*b, (rank+1)*b).  One reduce-scatter on RCCL; gloo has none, so all-reduce + slice there."""
+    if dist.get_backend(group) == "nccl":
+        out = torch.empty(b, full.shape[1], dtype=full.dtype, device=full.device)
+        dist.reduce_scatter_tensor(out, full.contiguous(), group=group)
+        return out
+    full = full.contiguous()
+    dist.all_reduce(full, group=group)
+    return full[rank * b:(rank + 1) * b]
+
+
+class _ClipLossFn(torch.autograd.Function):
+    """ClipLoss as an autograd node.  forward = the fused strip kernel; backward = ov_clip_loss_backward plus the routing of
+    the gathered-side gradient that the reference gets from autograd through gather_features (loss.py:19-63)."""
+
+    @staticmethod
+    def forward(ctx, mod: "ClipLoss", image_features, text_features, logit_scale):
+        ws, rank = mod.world_size, mod.rank
+        img, txt = image_features.detach().float().contiguous(), text_features.detach().float().contiguous()
+        b = img.shape[0]
+        if ws > 1:
+            all_img, all_txt = gather_features(img, txt, mod.local_loss, mod.gather_with_grad, rank, ws, mod.use_horovod)
+        else:
+            all_img, all_txt = img, txt
+        if ws > 1 and not mod.local_loss:
+            x_img, x_txt, off = all_img, all_txt, 0          # every rank evaluates the global loss (loss.py:111-113)
+        else:
+            x_img, x_txt, off = img, txt, b * rank
+        scale = float(logit_scale.detach())
+        loss = mod._loss_strips(x_img, x_txt, all_img, all_txt, scale, off)
+        ctx.mod, ctx.scale, ctx.off, ctx.b = mod, scale, off, b
+        ctx.in_dtypes = (image_features.dtype, text_features.dtype, logit_scale.dtype)
+        ctx.save_for_backward(x_img, x_txt, all_img, all_txt, mod.last_terms)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        mod: "ClipLoss" = ctx.mod
+        x_img, x_txt, all_img, all_txt, terms = ctx.saved_tensors
+        lib = _lib.load()
+        ws, rank, b = mod.world_size, mod.rank, ctx.b
+        bx, e = x_img.shape
+        n = all_img.shape[0]
+        # the gathered side carries gradient when it IS the local tensor (world_size 1), when the own chunk was put back
+        # (not local_loss, loss.py:57-59) or when the gather itself is differentiable (gather_with_grad)
+        gathered_grad = ws == 1 or not mod.local_loss or mod.gather_with_grad
+        d_img, d_txt = torch.empty_like(x_img), torch.empty_like(x_txt)
+        d_all = torch.empty(2, n, e, dtype=torch.float32, device=x_img.device) if gathered_grad else None
+        d_scale = torch.empty(1, dtype=torch.float32, device=x_img.device)
+        nbytes = lib.ov_clip_loss_backward_workspace_bytes(bx, n)
+        wsb = torch.empty(nbytes + 256, dtype=torch.uint8, device=x_img.device)
+        check(lib.ov_clip_loss_backward(ptr(x_img), ptr(x_txt), ptr(all_img), ptr(all_txt), bx, n, e, ctx.scale, ctx.off, ptr(terms),
+                                        float(grad_out), ptr(d_img), ptr(d_txt), ptr(d_all[0]) if gathered_grad else None,
+                                        ptr(d_all[1]) if gathered_grad else None, ptr(d_scale), ptr(wsb), nbytes, stream_ptr()),
+              "ov_clip_loss_backward")
+        if ws == 1:
+            g_img, g_txt = d_img + d_all[0], d_txt + d_all[1]
+        elif mod.local_loss:
+            g_img, g_txt = d_img, d_txt
+            if mod.gather_with_grad:
+                own = _sum_over_ranks_own_chunk(torch.cat([d_all[0], d_all[1]], dim=1), b, rank)
+                g_img, g_txt = g_img + own[:, :e], g_txt + own[:, e:]
+        else:
+            tot = torch.cat([d_img + d_all[0], d_txt + d_all[1]], dim=1)          # [N, 2E]: both sides are the global set
+            own = _sum_over_ranks_own_chunk(tot, b, rank) if mod.gather_with_grad else tot[rank * b:(rank + 1) * b]
+            g_img, g_txt = own[:, :e], own[:, e:]
+        dt_i, dt_t, dt_s = ctx.in_dtypes
+        return None, g_img.to(dt_i), g_txt.to(dt_t), d_scale[0].to(dt_s)

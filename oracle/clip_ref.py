@@ -161,6 +161,60 @@ def clip_loss(img: torch.Tensor, txt: torch.Tensor, logit_scale, all_img: Option
     return (F.cross_entropy(li, labels) + F.cross_entropy(lt, labels)) / 2
 
 
+def clip_loss_grads(img, txt, logit_scale, all_img=None, all_txt=None, rank: int = 0):
+    """Closed-form gradient of ``clip_loss`` (what autograd gives the reference through loss.py:102-131), with every argument
+    treated as an independent leaf:  P = (softmax(logits) - onehot) / (2 b) per direction, then
+        d img = s P_i all_txt,  d txt = s P_t all_img,  d all_txt = s P_i^T img,  d all_img = s P_t^T txt,
+        d s   = sum P_i * (img all_txt^T) + sum P_t * (txt all_img^T).
+    Returns (d_img, d_txt, d_all_img, d_all_txt, d_scale); the caller adds / routes the gathered-side terms the way
+    gather_features (loss.py:19-63) makes them flow."""
+    if all_img is None:
+        all_img, all_txt = img, txt
+    img, txt, all_img, all_txt = img.float(), txt.float(), all_img.float(), all_txt.float()
+    s = float(logit_scale)
+    b = img.shape[0]
+    di, dt = img @ all_txt.T, txt @ all_img.T
+    idx = torch.arange(b) + b * rank
+    pi, pt = torch.softmax(s * di, 1), torch.softmax(s * dt, 1)
+    pi[torch.arange(b), idx] -= 1.0
+    pt[torch.arange(b), idx] -= 1.0
+    pi, pt = pi / (2 * b), pt / (2 * b)
+    return (s * pi @ all_txt, s * pt @ all_img, s * pt.T @ txt, s * pi.T @ img, (pi * di).sum() + (pt * dt).sum())
+
+
+def clip_loss_backward_ranks(img_all, txt_all, logit_scale, ws: int, local_loss: bool, gather_with_grad: bool):
+    """Per-rank (d image_features, d text_features, d logit_scale) of ClipLoss at world_size ``ws`` from the full feature
+    sets, routing the gathered-side gradient as gather_features does (loss.py:39-61): detached gather -> nothing flows back
+    except through the own chunk put back when ``not local_loss`` (:57-59); ``gather_with_grad`` -> the backward of
+    torch.distributed.nn.all_gather sums every rank's gathered-side gradient and hands each rank its own rows."""
+    n, e = img_all.shape
+    b = n // ws
+    per = []
+    for r in range(ws):
+        sl = slice(r * b, (r + 1) * b)
+        if local_loss:
+            per.append(clip_loss_grads(img_all[sl], txt_all[sl], logit_scale, img_all, txt_all, r))
+        else:
+            per.append(clip_loss_grads(img_all, txt_all, logit_scale, img_all, txt_all, 0))
+    out = []
+    for r in range(ws):
+        sl = slice(r * b, (r + 1) * b)
+        d_img, d_txt, d_ai, d_at, d_s = per[r]
+        if local_loss:
+            gi, gt = d_img.clone(), d_txt.clone()
+            if gather_with_grad:
+                gi += sum(p[2] for p in per)[sl]
+                gt += sum(p[3] for p in per)[sl]
+        else:
+            if gather_with_grad:
+                gi = sum(p[0] + p[2] for p in per)[sl]
+                gt = sum(p[1] + p[3] for p in per)[sl]
+            else:
+                gi, gt = (d_img + d_ai)[sl], (d_txt + d_at)[sl]
+        out.append((gi, gt, d_s))
+    return out
+
+
 def clip_loss_terms(img, txt, logit_scale, all_img=None, all_txt=None, rank: int = 0):
     """Per-row LSE and diagonal logits of both directions (what the fused HIP kernel emits)."""
     if all_img is None:

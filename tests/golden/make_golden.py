@@ -19,6 +19,7 @@ Files written (np.savez_compressed):
   large14_224.npz         L/14@224 + text-L, B=2: features (fp32 and the reference's bf16 mode), token slices
   small8_384.npz          S/8@384, B=1 (2305 tokens): features, token slices
   cliploss_ws.npz         ClipLoss(local_loss=True) per-rank losses at world_size 2 and 8 over gloo
+  cliploss_grad.npz       autograd gradients of ClipLoss at world_size 1 and per rank at world_size 2
 """
 from __future__ import annotations
 
@@ -272,6 +273,65 @@ def gen_cliploss(lossmod, ref_root, out):
     np.savez_compressed(out, **res)
 
 
+def _lossgrad_worker(rank, ws, store, ref_root, feats, q):
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method=f"file://{store}", rank=rank, world_size=ws)
+    _, lossmod, _ = import_reference(ref_root)
+    img, txt, s = feats
+    b = img.shape[0] // ws
+    res = {}
+    for local_loss in (True, False):
+        for gwg in (False, True):
+            li = img[rank * b:(rank + 1) * b].clone().requires_grad_(True)
+            lt = txt[rank * b:(rank + 1) * b].clone().requires_grad_(True)
+            sc = s.clone().requires_grad_(True)
+            fn = lossmod.ClipLoss(local_loss=local_loss, gather_with_grad=gwg, rank=rank, world_size=ws)
+            try:
+                l = fn(li, lt, sc)
+                l.backward()
+                res[(local_loss, gwg)] = (float(l), f32(li.grad), f32(lt.grad), float(sc.grad))
+            except Exception as e:      # gloo has no all_to_all for torch.distributed.nn.all_gather's backward
+                res[(local_loss, gwg)] = repr(e)
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def gen_lossgrad(lossmod, ref_root, out):
+    """Gradients of the reference ClipLoss (loss.py:19-131) by autograd: d loss / d (image_features, text_features,
+    logit_scale) at world_size 1, and per rank at world_size 2 over gloo for local_loss x gather_with_grad."""
+    import torch.multiprocessing as mp
+    g = torch.Generator().manual_seed(7)
+    n, e = 48, 192
+    img = torch.nn.functional.normalize(torch.randn(n, e, generator=g), dim=-1)
+    txt = torch.nn.functional.normalize(img * 0.5 + torch.randn(n, e, generator=g) * 0.08, dim=-1)
+    s = torch.tensor(1.0 / 0.07)
+    res = {"img": f32(img), "txt": f32(txt), "scale": f32(s)}
+    a, b_, c = img.clone().requires_grad_(True), txt.clone().requires_grad_(True), s.clone().requires_grad_(True)
+    l = lossmod.ClipLoss()(a, b_, c)
+    l.backward()
+    res.update(loss_ws1=f32(l), dimg_ws1=f32(a.grad), dtxt_ws1=f32(b_.grad), dscale_ws1=f32(c.grad))
+    ws = 2
+    ctx = mp.get_context("spawn")
+    with tempfile.TemporaryDirectory() as d:
+        q = ctx.Queue()
+        ps = [ctx.Process(target=_lossgrad_worker, args=(r, ws, os.path.join(d, "store"), ref_root, (img, txt, s), q))
+              for r in range(ws)]
+        [p.start() for p in ps]
+        got = dict(q.get(timeout=600) for _ in range(ws))
+        [p.join() for p in ps]
+    for (local_loss, gwg) in got[0]:
+        tag = f"ws2_local{int(local_loss)}_gwg{int(gwg)}"
+        if isinstance(got[0][(local_loss, gwg)], str):
+            print("  not captured:", tag, got[0][(local_loss, gwg)][:200])
+            continue
+        res[tag + "_loss"] = np.array([got[r][(local_loss, gwg)][0] for r in range(ws)], dtype=np.float64)
+        res[tag + "_dimg"] = np.stack([got[r][(local_loss, gwg)][1] for r in range(ws)])
+        res[tag + "_dtxt"] = np.stack([got[r][(local_loss, gwg)][2] for r in range(ws)])
+        res[tag + "_dscale"] = np.array([got[r][(local_loss, gwg)][3] for r in range(ws)], dtype=np.float64)
+    np.savez_compressed(out, **res)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -288,6 +348,7 @@ def main():
         "small": lambda: gen_small(m, os.path.join(HERE, "small8_384.npz")),
         "cliploss": lambda: gen_cliploss(lossmod, a.ref, os.path.join(HERE, "cliploss_ws.npz")),
         "preprocess": lambda: gen_preprocess(a.ref, os.path.join(HERE, "preprocess.npz")),
+        "lossgrad": lambda: gen_lossgrad(lossmod, a.ref, os.path.join(HERE, "cliploss_grad.npz")),
     }
     for k, fn in jobs.items():
         if a.only and k not in a.only.split(","):

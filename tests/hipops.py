@@ -124,3 +124,20 @@ def attention_fp8out(qkv, B, L, Hh, amax, amax_next=None):
     check(lib.ov_attention_fp8out(ptr(qkv), qkv.stride(0), ptr(out), out.stride(0), B, L, Hh, 64, 0.125, ptr(amax),
                                   ptr(amax_next) if amax_next is not None else None, stream_ptr()))
     return out
+
+
+def clip_loss_backward(img, txt, all_img, all_txt, scale, label_offset, terms, grad=1.0, gathered=True):
+    """ov_clip_loss_backward: returns (d_img, d_txt, d_all_img | None, d_all_txt | None, d_scale)."""
+    lib = _lib.load()
+    b, e = img.shape
+    n = all_img.shape[0]
+    d_img, d_txt = torch.empty_like(img), torch.empty_like(txt)
+    d_ai = torch.empty_like(all_img) if gathered else None
+    d_at = torch.empty_like(all_txt) if gathered else None
+    d_s = torch.empty(1, dtype=torch.float32, device=img.device)
+    nb = lib.ov_clip_loss_backward_workspace_bytes(b, n)
+    ws = torch.empty(nb + 256, dtype=torch.uint8, device=img.device)
+    check(lib.ov_clip_loss_backward(ptr(img), ptr(txt), ptr(all_img), ptr(all_txt), b, n, e, float(scale), label_offset, ptr(terms),
+                                    float(grad), ptr(d_img), ptr(d_txt), ptr(d_ai) if gathered else None,
+                                    ptr(d_at) if gathered else None, ptr(d_s), ptr(ws), nb, stream_ptr()), "ov_clip_loss_backward")
+    return d_img, d_txt, d_ai, d_at, d_s

@@ -58,6 +58,9 @@ def test_argument_validation_of_the_widening_entry_points():
     assert lib.ov_gemm_fp8(None, 1024, None, 1024, None, None, None, None, 1024, 256, 256, 1024, 0, None, 0, None) == -1
     assert lib.ov_gemm_fp8_static(None, 1024, None, 1024, None, None, None, None, None, 1024, None, None, 256, 256, 1024, 1, None, 0, None) == -1
     assert lib.ov_amax_roll(None, None, 4, None) == -1
+    # loss backward: null pointers are rejected; the workspace holds one partial per 32-row tile and direction
+    assert lib.ov_clip_loss_backward(None, None, None, None, 16, 16, 192, 1.0, 0, None, 1.0, None, None, None, None, None, None, 0, None) == -1
+    assert lib.ov_clip_loss_backward_workspace_bytes(256, 2048) >= 2 * 8 * 4
     assert lib.ov_quant_rows_fp8(None, 1024, None, 1024, None, 4, 1024, None, None) == -1
     assert lib.ov_layernorm_quant_fp8(None, 1024, None, None, None, 1024, None, 4, 1024, 1e-6, None) == -1
     assert lib.ov_attention_fp8out(None, 192, None, 64, 1, 32, 1, 64, 0.125, None, None, None) == -1

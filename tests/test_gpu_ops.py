@@ -3,6 +3,8 @@
 Tolerances are stated per test.  bf16 has 8 significant bits (eps = 2^-8 = 3.9e-3 relative), so an
 operator with bf16 output is compared with rtol ~ 1e-2 against the oracle evaluated in fp32 on the SAME
 bf16-rounded inputs; fp32-output operators (LN stats, l2norm, logits, loss) get fp32-level tolerances."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -169,6 +171,99 @@ def test_clip_loss_golden_reference_ranks():
             l, _ = H.clip_loss(img[r * b:(r + 1) * b].contiguous().to(DEV), txt[r * b:(r + 1) * b].contiguous().to(DEV),
                                img.to(DEV), txt.to(DEV), s, r * b)
             assert abs(float(l) - float(g[f"local_losses_ws{ws}"][r])) < 1e-5
+
+
+@pytest.mark.parametrize("b,N,E,off", [(16, 16, 192, 0), (4, 16, 192, 8), (256, 256, 768, 0), (100, 700, 384, 300),
+                                       (33, 2100, 1152, 2000), (24, 48, 32, 24)])
+def test_clip_loss_backward_vs_oracle(b, N, E, off):
+    """ov_clip_loss_backward (local-side, gathered-side and scale gradients) vs the oracle's closed form; fp32 MFMA, so the
+    tolerance is a few ulps of the largest term (1e-6 absolute on gradients of magnitude <= ~0.1)."""
+    from oracle import clip_ref as R
+    ai = torch.nn.functional.normalize(rnd(N, E, seed=32), dim=-1)
+    at = torch.nn.functional.normalize(ai * 0.5 + rnd(N, E, seed=33) * 0.05, dim=-1)
+    img, txt = ai[off:off + b].contiguous(), at[off:off + b].contiguous()
+    s = 1 / 0.07
+    _, terms = H.clip_loss(img.to(DEV), txt.to(DEV), ai.to(DEV), at.to(DEV), s, off)
+    got = H.clip_loss_backward(img.to(DEV), txt.to(DEV), ai.to(DEV), at.to(DEV), s, off, terms, grad=0.5)
+    # the oracle's rank argument is off / b; keep arbitrary offsets by differentiating the shifted problem directly
+    di, dt = img @ at.T, txt @ ai.T
+    idx = torch.arange(b) + off
+    pi, pt = torch.softmax(s * di, 1), torch.softmax(s * dt, 1)
+    pi[torch.arange(b), idx] -= 1
+    pt[torch.arange(b), idx] -= 1
+    pi, pt = 0.5 * pi / (2 * b), 0.5 * pt / (2 * b)
+    want = (s * pi @ at, s * pt @ ai, s * pt.T @ txt, s * pi.T @ img, (pi * di).sum() + (pt * dt).sum())
+    if off % b == 0:                         # and the oracle itself where its labelling applies
+        ref = R.clip_loss_grads(img, txt, s, ai, at, off // b)
+        for w, r in zip(want, ref):
+            assert (w - 0.5 * r).abs().max() < 1e-6
+    for name, g_, w in zip(("d_img", "d_txt", "d_all_img", "d_all_txt"), got[:4], want[:4]):
+        np.testing.assert_allclose(g_.cpu().numpy(), w.numpy(), rtol=2e-4, atol=1e-6, err_msg=name)
+    assert abs(float(got[4]) - float(want[4])) < 2e-6 + 2e-4 * abs(float(want[4]))
+    only_local = H.clip_loss_backward(img.to(DEV), txt.to(DEV), ai.to(DEV), at.to(DEV), s, off, terms, grad=0.5, gathered=False)
+    assert only_local[2] is None and torch.equal(only_local[0], got[0]) and torch.equal(only_local[1], got[1])   # deterministic
+
+
+def test_clip_loss_autograd_golden_world_size_1():
+    """openvision_amd.ClipLoss as an autograd node vs autograd through the reference ClipLoss (cliploss_grad.npz)."""
+    from conftest import golden
+    from openvision_amd.loss import ClipLoss
+    g = golden("cliploss_grad.npz")
+    img = torch.from_numpy(g["img"]).to(DEV).requires_grad_(True)
+    txt = torch.from_numpy(g["txt"]).to(DEV).requires_grad_(True)
+    s = torch.from_numpy(g["scale"]).to(DEV).requires_grad_(True)
+    loss = ClipLoss()(img, txt, s)
+    assert abs(float(loss.detach()) - float(g["loss_ws1"])) < 1e-5
+    (loss * 1.0).backward()
+    np.testing.assert_allclose(img.grad.cpu().numpy(), g["dimg_ws1"], rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(txt.grad.cpu().numpy(), g["dtxt_ws1"], rtol=2e-4, atol=1e-6)
+    assert abs(float(s.grad) - float(g["dscale_ws1"])) < 2e-6
+    with torch.no_grad():                                        # the forward-only path is unchanged
+        assert abs(float(ClipLoss()(img, txt, s)) - float(g["loss_ws1"])) < 1e-5
+
+
+def _lossgrad_rank(rank, ws, store, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    from conftest import golden
+    from openvision_amd.loss import ClipLoss
+    dist.init_process_group("gloo", init_method=f"file://{store}", rank=rank, world_size=ws)
+    g = golden("cliploss_grad.npz")
+    b = g["img"].shape[0] // ws
+    worst = {}
+    for local_loss in (True, False):
+        for gwg in (False, True):
+            tag = f"ws2_local{int(local_loss)}_gwg{int(gwg)}"
+            img = torch.from_numpy(g["img"][rank * b:(rank + 1) * b]).to(DEV).requires_grad_(True)
+            txt = torch.from_numpy(g["txt"][rank * b:(rank + 1) * b]).to(DEV).requires_grad_(True)
+            s = torch.from_numpy(g["scale"]).to(DEV).requires_grad_(True)
+            loss = ClipLoss(local_loss=local_loss, gather_with_grad=gwg, rank=rank, world_size=ws)(img, txt, s)
+            loss.backward()
+            worst[tag] = (abs(float(loss.detach()) - float(g[tag + "_loss"][rank])),
+                          float((img.grad.cpu() - torch.from_numpy(g[tag + "_dimg"][rank])).abs().max()),
+                          float((txt.grad.cpu() - torch.from_numpy(g[tag + "_dtxt"][rank])).abs().max()),
+                          abs(float(s.grad) - float(g[tag + "_dscale"][rank])))
+    q.put((rank, worst))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_clip_loss_autograd_golden_world_size_2():
+    """Two ranks (gloo rendezvous, both on this one GPU): loss and gradients per rank vs the reference's, for every
+    local_loss x gather_with_grad routing of gather_features (loss.py:19-63)."""
+    import tempfile
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    with tempfile.TemporaryDirectory() as d:
+        q = ctx.Queue()
+        ps = [ctx.Process(target=_lossgrad_rank, args=(r, 2, os.path.join(d, "store"), q)) for r in range(2)]
+        [p.start() for p in ps]
+        res = dict(q.get(timeout=300) for _ in range(2))
+        [p.join(60) for p in ps]
+    for rank in range(2):
+        for tag, (dl, di, dt, ds) in res[rank].items():
+            assert dl < 1e-5 and di < 2e-6 and dt < 2e-6 and ds < 2e-6, (rank, tag, dl, di, dt, ds)
 
 
 @pytest.mark.parametrize("M,N,K,epi", [(256, 256, 384, 0), (300, 520, 512, 0), (771, 3072, 1024, 1), (2048, 1024, 4096, 3),

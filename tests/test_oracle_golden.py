@@ -112,3 +112,22 @@ def test_cliploss_local_losses_match_reference_ranks():
         np.testing.assert_allclose(mine, g[f"local_losses_ws{ws}"], atol=1e-6)
         # mean over ranks of the local losses == the global single-process loss
         assert abs(np.mean(mine) - float(g["loss_ws1"])) < 1e-6
+
+
+def test_oracle_loss_gradients_match_reference_autograd():
+    """oracle.clip_loss_grads / clip_loss_backward_ranks (closed form) vs autograd through the reference ClipLoss
+    (tests/golden/cliploss_grad.npz: world_size 1, and per rank at world_size 2 for local_loss x gather_with_grad)."""
+    g = golden("cliploss_grad.npz")
+    img, txt, s = torch.from_numpy(g["img"]), torch.from_numpy(g["txt"]), torch.from_numpy(g["scale"])
+    d_img, d_txt, d_ai, d_at, d_s = R.clip_loss_grads(img, txt, s)
+    assert (d_img + d_ai - torch.from_numpy(g["dimg_ws1"])).abs().max() < 2e-6
+    assert (d_txt + d_at - torch.from_numpy(g["dtxt_ws1"])).abs().max() < 2e-6
+    assert abs(float(d_s) - float(g["dscale_ws1"])) < 2e-6
+    for local_loss in (True, False):
+        for gwg in (False, True):
+            tag = f"ws2_local{int(local_loss)}_gwg{int(gwg)}"
+            got = R.clip_loss_backward_ranks(img, txt, s, 2, local_loss, gwg)
+            for r in range(2):
+                assert (got[r][0] - torch.from_numpy(g[tag + "_dimg"][r])).abs().max() < 2e-6, tag
+                assert (got[r][1] - torch.from_numpy(g[tag + "_dtxt"][r])).abs().max() < 2e-6, tag
+                assert abs(float(got[r][2]) - float(g[tag + "_dscale"][r])) < 2e-6, tag
