@@ -219,6 +219,33 @@ int ov_clip_loss_backward(const float* img, const float* txt, const float* all_i
                           float* d_txt, float* d_all_img, float* d_all_txt, float* d_scale, void* workspace,
                           size_t workspace_bytes, ov_stream_t stream);
 
+/* ---- operator-level backward of the block (the reference gets these from torch autograd through nn.Linear,
+ * nn.LayerNorm and nn.GELU: transformer.py:15-30, 232-236).  bf16 activations and gradients, fp32 arithmetic and parameter-gradient
+ * sums, deterministic (two-stage reductions in a fixed order). ---------------------------------------------------------------- */
+
+/* out[c, r] = in[r, c]; columns rows..pad64(rows)-1 of out are written as zeros (the GEMM's K granule).  cols % 8 == 0,
+ * ld_out >= pad64(rows). */
+int ov_transpose_bf16(const ov_bf16* in, int64_t ld_in, int64_t rows, int cols, ov_bf16* out, int64_t ld_out, ov_stream_t stream);
+
+/* y = x W^T + b  (x [M, K], W [N, K], dY [M, N]):  dX = dY W  [M, K],  dW = dY^T x  [N, K] (bf16),  db = column sums of dY (fp32 [N]).
+ * Any of dX / dW / db may be NULL (skipped).  N % 64 == 0, K % 64 == 0.  Both products run on ov_gemm, fed by LDS-staged transposes
+ * held in the workspace (ov_linear_backward_workspace_bytes). */
+size_t ov_linear_backward_workspace_bytes(int64_t M, int N, int K);
+int ov_linear_backward(const ov_bf16* dY, int64_t lddy, const ov_bf16* X, int64_t ldx, const ov_bf16* W, int64_t ldw, int64_t M, int N,
+                       int K, ov_bf16* dX, int64_t lddx, ov_bf16* dW, int64_t lddw, float* db, void* workspace,
+                       size_t workspace_bytes, ov_stream_t stream);
+
+/* Backward of ov_layernorm on bf16 rows: dx = rstd (q - mean(q) - xhat mean(q xhat)) with q = dy * gamma, dgamma = sum_rows dy * xhat,
+ * dbeta = sum_rows dy (fp32 [D]).  D % 8 == 0, D <= 4096. */
+size_t ov_layernorm_backward_workspace_bytes(int64_t rows, int D);
+int ov_layernorm_backward(const ov_bf16* x, int64_t ldx, const float* gamma, const ov_bf16* dy, int64_t lddy, ov_bf16* dx, int64_t lddx,
+                          float* dgamma, float* dbeta, int64_t rows, int D, float eps, void* workspace, size_t workspace_bytes,
+                          ov_stream_t stream);
+
+/* da = dh * gelu'(a) on the pre-activation a [rows, N] (tanh_form = 0: exact erf GELU, vision; 1: tanh form, text).  N % 8 == 0. */
+int ov_gelu_backward(const ov_bf16* a, int64_t lda, const ov_bf16* dh, int64_t lddh, ov_bf16* da, int64_t ldda, int64_t rows, int N,
+                     int tanh_form, ov_stream_t stream);
+
 /* ---- in-situ kernel timing (used by bench.py for the roofline object; off by default) ------------------
  * ov_profile_enable(mask, n): bracket every launch of the selected classes inside ov_tower_forward with a pair
  * of HIP events recorded on the launch stream (n = max launches recorded; resets earlier records; mask 0 = off).

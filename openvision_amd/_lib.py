@@ -85,6 +85,14 @@ SIGNATURES = {
     "ov_clip_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p,
                              c_void_p, c_void_p, c_size_t, c_void_p]),
     "ov_clip_loss_backward_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "ov_transpose_bf16": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p]),
+    "ov_linear_backward_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
+    "ov_linear_backward": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_int64,
+                                   c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "ov_layernorm_backward_workspace_bytes": (c_size_t, [c_int64, c_int]),
+    "ov_layernorm_backward": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
+                                      c_int, c_float, c_void_p, c_size_t, c_void_p]),
+    "ov_gelu_backward": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
     "ov_clip_loss_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p,
                                       c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "ov_profile_enable": (c_int, [C.c_uint, c_int]),

@@ -1,0 +1,326 @@
+// backward.hip — operator-level backward kernels of the block (gfx950): the second piece of SURVEY §8f row 4.
+//
+// The reference has no backward code of its own: it is torch autograd through nn.Linear / nn.LayerNorm / nn.GELU
+// (open_clip/transformer.py:15-30, 232-236).  What autograd computes for those modules is restated here:
+//   Linear     y = x W^T + b     ->  dx = dy W,  dW = dy^T x,  db = sum_rows dy
+//   LayerNorm  y = xhat g + b    ->  dx = rstd (q - mean(q) - xhat mean(q xhat)), q = dy g;  dg = sum dy xhat;  db = sum dy
+//   GELU       h = gelu(a)       ->  da = dh gelu'(a)     (exact erf for the vision tower, tanh form for the text tower)
+// The two Linear products run on the tuned forward GEMM (ov_gemm: C = A W^T with K contiguous on both operands), fed by
+// bf16 transposes staged through LDS (HBM-bound); everything else is one HBM pass with fp32 arithmetic.  Reductions over
+// rows are two-stage with a fixed order (no atomics): results are deterministic.
+#include "common.h"
+
+extern "C" int ov_gemm(const ov_bf16* A, int64_t lda, const ov_bf16* W, int64_t ldw, const float* bias, ov_bf16* C, int64_t ldc,
+                       int64_t M, int N, int K, int epilogue, const ov_bf16* R, int64_t ldr, int out_group, int resid_mod,
+                       int resid_off, ov_stream_t stream);
+
+namespace {
+
+// out[c, r] = in[r, c] for r < R, 0 for R <= r < Rpad (Rpad = R rounded up to 64: the GEMM's K granule).  64 x 64 tiles.
+__global__ __launch_bounds__(256) void transpose_bf16(const unsigned short* __restrict__ in, int64_t ld_in, int64_t R, int C,
+                                                      unsigned short* __restrict__ out, int64_t ld_out) {
+    __shared__ unsigned short tile[64][66];                       // tile[c][r], 33-dword rows: conflict-free both ways
+    const int64_t r0 = (int64_t)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 64;
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int r = (t >> 3) + 32 * h, c8 = (t & 7) * 8;
+        u32x4_t w = {0u, 0u, 0u, 0u};
+        if (r0 + r < R && c0 + c8 < C) w = *(const u32x4_t*)(in + (r0 + r) * ld_in + c0 + c8);   // C % 8 == 0
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            tile[c8 + 2 * e][r] = (unsigned short)(w[e] & 0xffffu);
+            tile[c8 + 2 * e + 1][r] = (unsigned short)(w[e] >> 16);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int c = (t >> 3) + 32 * h, r8 = (t & 7) * 8;
+        if (c0 + c < C) {
+            u32x4_t w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = (unsigned)tile[c][r8 + 2 * e] | ((unsigned)tile[c][r8 + 2 * e + 1] << 16);
+            *(u32x4_t*)(out + (int64_t)(c0 + c) * ld_out + r0 + r8) = w;       // r0 + r8 < Rpad by construction
+        }
+    }
+}
+
+// Column sums of a bf16 [M, N] matrix in fp32: stage 1 sums 256-row chunks (a thread owns two adjacent columns).
+constexpr int CS_ROWS = 256;
+__global__ __launch_bounds__(256) void colsum_partial(const unsigned int* __restrict__ x, int64_t ld2, int64_t M, int N2,
+                                                      float* __restrict__ part) {
+    const int c2 = blockIdx.x * 256 + threadIdx.x;                 // column pair
+    if (c2 >= N2) return;
+    const int64_t m0 = (int64_t)blockIdx.y * CS_ROWS;
+    const int64_t m1 = m0 + CS_ROWS < M ? m0 + CS_ROWS : M;
+    float s0 = 0.f, s1 = 0.f;
+    for (int64_t m = m0; m < m1; ++m) {
+        const unsigned int w = x[m * ld2 + c2];
+        s0 += bf16lo_to_f32(w);
+        s1 += bf16hi_to_f32(w);
+    }
+    float2* p = (float2*)(part + ((int64_t)blockIdx.y * N2 + c2) * 2);
+    *p = make_float2(s0, s1);
+}
+// out[n] = sum over `nrow` partial rows (fixed order)
+__global__ __launch_bounds__(256) void rows_sum(const float* __restrict__ part, int64_t nrow, int N, int64_t stride,
+                                                float* __restrict__ out) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int64_t r = 0; r < nrow; ++r) s += part[r * stride + n];
+    out[n] = s;
+}
+
+// LayerNorm backward, wave per row (row in registers, like the forward).  dgamma / dbeta partial sums stay in the wave's
+// registers across the rows it owns and are written once: part[wave_global][2][D].
+template <int NCH>
+__global__ __launch_bounds__(256) void layernorm_bwd_rows(const ov_bf16* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
+                                                          const ov_bf16* __restrict__ dy, int64_t lddy, ov_bf16* __restrict__ dx,
+                                                          int64_t lddx, int64_t rows, int D, float eps, float* __restrict__ part) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nchunk = D >> 3;
+    const float invD = 1.0f / (float)D;
+    float ag[NCH][8], ab[NCH][8];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { ag[c][e] = 0.f; ab[c][e] = 0.f; }
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        float v[NCH][8], q[NCH][8];
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int ch = lane + c * 64;
+            if (ch < nchunk) {
+                const u32x4_t w = *(const u32x4_t*)(x + row * ldx + ch * 8);
+                const u32x4_t d = *(const u32x4_t*)(dy + row * lddy + ch * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[c][2 * e] = bf16lo_to_f32(w[e]); v[c][2 * e + 1] = bf16hi_to_f32(w[e]);
+                    q[c][2 * e] = bf16lo_to_f32(d[e]); q[c][2 * e + 1] = bf16hi_to_f32(d[e]);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += v[c][e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { v[c][e] = 0.f; q[c][e] = 0.f; }
+            }
+        }
+        const float mean = wave_sum(s) * invD;
+        float ss = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+            if (lane + c * 64 < nchunk)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = v[c][e] - mean; ss += d * d; }
+        const float rstd = rsqrtf(wave_sum(ss) * invD + eps);
+        float sq = 0.f, sqx = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int ch = lane + c * 64;
+            if (ch < nchunk) {
+                const float4 g0 = *(const float4*)(gamma + ch * 8), g1 = *(const float4*)(gamma + ch * 8 + 4);
+                const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float xh = (v[c][e] - mean) * rstd;
+                    ag[c][e] = fmaf(q[c][e], xh, ag[c][e]);          // dgamma += dy * xhat
+                    ab[c][e] += q[c][e];                             // dbeta  += dy
+                    v[c][e] = xh;
+                    q[c][e] *= g[e];                                 // q = dy * gamma
+                    sq += q[c][e];
+                    sqx = fmaf(q[c][e], xh, sqx);
+                }
+            }
+        }
+        const float mq = wave_sum(sq) * invD, mqx = wave_sum(sqx) * invD;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int ch = lane + c * 64;
+            if (ch < nchunk) {
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = rstd * (q[c][e] - mq - v[c][e] * mqx);
+                const u32x4_t w = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+                *(u32x4_t*)(dx + row * lddx + ch * 8) = w;
+            }
+        }
+    }
+    float* pg = part + ((int64_t)blockIdx.x * 4 + wave) * 2 * D;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int ch = lane + c * 64;
+        if (ch < nchunk) {
+            *(float4*)(pg + ch * 8) = make_float4(ag[c][0], ag[c][1], ag[c][2], ag[c][3]);
+            *(float4*)(pg + ch * 8 + 4) = make_float4(ag[c][4], ag[c][5], ag[c][6], ag[c][7]);
+            *(float4*)(pg + D + ch * 8) = make_float4(ab[c][0], ab[c][1], ab[c][2], ab[c][3]);
+            *(float4*)(pg + D + ch * 8 + 4) = make_float4(ab[c][4], ab[c][5], ab[c][6], ab[c][7]);
+        }
+    }
+}
+
+// d gelu / d a.  erf form: Phi(a) + a phi(a), Phi through the same A&S 7.1.26 erfc as the forward epilogue's reference form;
+// tanh form: 0.5 (1 + t) + 0.5 a (1 - t^2) u'(a), t = tanh(u), u = sqrt(2/pi) (a + 0.044715 a^3).
+__device__ __forceinline__ float gelu_erf_grad(float a) {
+    const float z = fabsf(a) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(t, 1.061405429f, -1.453152027f);
+    p = fmaf(t, p, 1.421413741f);
+    p = fmaf(t, p, -0.284496736f);
+    p = fmaf(t, p, 0.254829592f);
+    p *= t;
+    const float ex = __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);      // exp(-a^2 / 2)
+    const float half_erfc = 0.5f * p * ex;
+    const float Phi = a >= 0.f ? 1.0f - half_erfc : half_erfc;
+    return fmaf(a * 0.3989422804014327f, ex, Phi);
+}
+__device__ __forceinline__ float gelu_tanh_grad(float a) {
+    const float a2 = a * a;
+    const float u = 0.7978845608028654f * a * fmaf(0.044715f, a2, 1.0f);
+    const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * u));   // sigmoid(2u) = (1 + tanh u) / 2
+    const float du = 0.7978845608028654f * fmaf(3.0f * 0.044715f, a2, 1.0f);
+    return fmaf(2.0f * a * sg * (1.0f - sg), du, sg);              // 0.5 (1 - t^2) = 2 sg (1 - sg)
+}
+
+template <bool TANH>
+__global__ __launch_bounds__(256) void gelu_bwd(const ov_bf16* __restrict__ a, int64_t lda, const ov_bf16* __restrict__ dh, int64_t lddh,
+                                                ov_bf16* __restrict__ da, int64_t ldda, int64_t rows, int nchunk) {
+    const int64_t total = rows * nchunk;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / nchunk;
+        const int c = (int)(i - r * nchunk) * 8;
+        const u32x4_t av = *(const u32x4_t*)(a + r * lda + c);
+        const u32x4_t dv = *(const u32x4_t*)(dh + r * lddh + c);
+        u32x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a0 = bf16lo_to_f32(av[e]), a1 = bf16hi_to_f32(av[e]);
+            const float g0 = TANH ? gelu_tanh_grad(a0) : gelu_erf_grad(a0);
+            const float g1 = TANH ? gelu_tanh_grad(a1) : gelu_erf_grad(a1);
+            o[e] = pack_bf16x2(bf16lo_to_f32(dv[e]) * g0, bf16hi_to_f32(dv[e]) * g1);
+        }
+        *(u32x4_t*)(da + r * ldda + c) = o;
+    }
+}
+
+inline int64_t pad64(int64_t v) { return (v + 63) / 64 * 64; }
+inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+
+int launch_transpose(const ov_bf16* in, int64_t ld_in, int64_t R, int C, ov_bf16* out, int64_t ld_out, hipStream_t st) {
+    const dim3 grid((unsigned)(pad64(R) / 64), (unsigned)((C + 63) / 64));
+    hipLaunchKernelGGL(transpose_bf16, grid, dim3(256), 0, st, (const unsigned short*)in, ld_in, R, C, (unsigned short*)out, ld_out);
+    OV_LAUNCH_CHECK();
+    return OV_OK;
+}
+
+}  // namespace
+
+extern "C" int ov_transpose_bf16(const ov_bf16* in, int64_t ld_in, int64_t rows, int cols, ov_bf16* out, int64_t ld_out,
+                                 ov_stream_t stream) {
+    if (!in || !out || rows <= 0 || cols <= 0) return OV_ERR_INVALID;
+    if (cols % 8 || ld_in % 8 || ld_out % 8 || ld_in < cols || ld_out < pad64(rows)) return OV_ERR_UNSUPPORTED;
+    if (((uintptr_t)in | (uintptr_t)out) & 15) return OV_ERR_INVALID;
+    if (pad64(rows) / 64 > 0x7fffffffLL) return OV_ERR_UNSUPPORTED;
+    return launch_transpose(in, ld_in, rows, cols, out, ld_out, (hipStream_t)stream);
+}
+
+extern "C" size_t ov_linear_backward_workspace_bytes(int64_t M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const int64_t mp = pad64(M);
+    return align256((size_t)K * N * 2) + align256((size_t)N * mp * 2) + align256((size_t)K * mp * 2) +
+           align256((size_t)((M + CS_ROWS - 1) / CS_ROWS) * N * 4);
+}
+
+extern "C" int ov_linear_backward(const ov_bf16* dY, int64_t lddy, const ov_bf16* X, int64_t ldx, const ov_bf16* W, int64_t ldw,
+                                  int64_t M, int N, int K, ov_bf16* dX, int64_t lddx, ov_bf16* dW, int64_t lddw, float* db,
+                                  void* workspace, size_t workspace_bytes, ov_stream_t stream) {
+    if (!dY || !X || !W || !workspace || M <= 0 || N <= 0 || K <= 0) return OV_ERR_INVALID;
+    if (!dX && !dW && !db) return OV_ERR_INVALID;
+    if (N % 64 || K % 64 || lddy % 8 || ldx % 8 || ldw % 8 || lddy < N || ldx < K || ldw < K) return OV_ERR_UNSUPPORTED;
+    if ((dX && (lddx % 8 || lddx < K)) || (dW && (lddw % 8 || lddw < K))) return OV_ERR_UNSUPPORTED;
+    if (((uintptr_t)dY | (uintptr_t)X | (uintptr_t)W | (uintptr_t)dX | (uintptr_t)dW | (uintptr_t)db | (uintptr_t)workspace) & 15)
+        return OV_ERR_INVALID;
+    if (workspace_bytes < ov_linear_backward_workspace_bytes(M, N, K)) return OV_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t mp = pad64(M);
+    char* ws = (char*)workspace;
+    ov_bf16* Wt = (ov_bf16*)ws;  ws += align256((size_t)K * N * 2);          // [K, N]
+    ov_bf16* dYt = (ov_bf16*)ws; ws += align256((size_t)N * mp * 2);         // [N, Mpad]
+    ov_bf16* Xt = (ov_bf16*)ws;  ws += align256((size_t)K * mp * 2);         // [K, Mpad]
+    float* part = (float*)ws;
+    int rc;
+    if (dX) {       // dX[M, K] = dY[M, N] . W[N, K]  =  ov_gemm(A = dY, "W" = W^T [K, N]) contracting over N
+        if ((rc = launch_transpose(W, ldw, N, K, Wt, N, st)) != OV_OK) return rc;
+        if ((rc = ov_gemm(dY, lddy, Wt, N, nullptr, dX, lddx, M, K, N, OV_EPI_BIAS, nullptr, 0, 0, 0, 0, stream)) != OV_OK) return rc;
+    }
+    if (dW) {       // dW[N, K] = dY^T[N, M] . X[M, K]  =  ov_gemm(A = dY^T [N, Mpad], "W" = X^T [K, Mpad]) contracting over Mpad (zeros past M)
+        if ((rc = launch_transpose(dY, lddy, M, N, dYt, mp, st)) != OV_OK) return rc;
+        if ((rc = launch_transpose(X, ldx, M, K, Xt, mp, st)) != OV_OK) return rc;
+        if (mp > 0x7fffffffLL) return OV_ERR_UNSUPPORTED;
+        if ((rc = ov_gemm(dYt, mp, Xt, mp, nullptr, dW, lddw, N, K, (int)mp, OV_EPI_BIAS, nullptr, 0, 0, 0, 0, stream)) != OV_OK) return rc;
+    }
+    if (db) {
+        const int64_t nchunk = (M + CS_ROWS - 1) / CS_ROWS;
+        if (nchunk > 65535) return OV_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(colsum_partial, dim3((unsigned)((N / 2 + 255) / 256), (unsigned)nchunk), dim3(256), 0, st,
+                           (const unsigned int*)dY, lddy / 2, M, N / 2, part);
+        OV_LAUNCH_CHECK();
+        hipLaunchKernelGGL(rows_sum, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, part, nchunk, N, (int64_t)N, db);
+        OV_LAUNCH_CHECK();
+    }
+    return OV_OK;
+}
+
+namespace {
+constexpr int LNB_BLOCKS = 512;
+inline int64_t lnb_blocks(int64_t rows) { const int64_t b = (rows + 3) / 4; return b < LNB_BLOCKS ? b : LNB_BLOCKS; }
+}
+
+extern "C" size_t ov_layernorm_backward_workspace_bytes(int64_t rows, int D) {
+    if (rows <= 0 || D <= 0) return 0;
+    return (size_t)lnb_blocks(rows) * 4 * 2 * D * sizeof(float);
+}
+
+extern "C" int ov_layernorm_backward(const ov_bf16* x, int64_t ldx, const float* gamma, const ov_bf16* dy, int64_t lddy, ov_bf16* dx,
+                                     int64_t lddx, float* dgamma, float* dbeta, int64_t rows, int D, float eps, void* workspace,
+                                     size_t workspace_bytes, ov_stream_t stream) {
+    if (!x || !gamma || !dy || !dx || !dgamma || !dbeta || !workspace || rows <= 0 || D <= 0) return OV_ERR_INVALID;
+    if (D % 8 || D > 4096 || ldx % 8 || lddy % 8 || lddx % 8 || ldx < D || lddy < D || lddx < D) return OV_ERR_UNSUPPORTED;
+    if (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)workspace) & 15) return OV_ERR_INVALID;
+    if (workspace_bytes < ov_layernorm_backward_workspace_bytes(rows, D)) return OV_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t blocks = lnb_blocks(rows);
+    const dim3 grid((unsigned)blocks), blk(256);
+    float* part = (float*)workspace;
+    const int nch = (D / 8 + 63) / 64;
+    if (nch <= 1) hipLaunchKernelGGL(layernorm_bwd_rows<1>, grid, blk, 0, st, x, ldx, gamma, dy, lddy, dx, lddx, rows, D, eps, part);
+    else if (nch <= 2) hipLaunchKernelGGL(layernorm_bwd_rows<2>, grid, blk, 0, st, x, ldx, gamma, dy, lddy, dx, lddx, rows, D, eps, part);
+    else if (nch <= 3) hipLaunchKernelGGL(layernorm_bwd_rows<3>, grid, blk, 0, st, x, ldx, gamma, dy, lddy, dx, lddx, rows, D, eps, part);
+    else if (nch <= 4) hipLaunchKernelGGL(layernorm_bwd_rows<4>, grid, blk, 0, st, x, ldx, gamma, dy, lddy, dx, lddx, rows, D, eps, part);
+    else hipLaunchKernelGGL(layernorm_bwd_rows<8>, grid, blk, 0, st, x, ldx, gamma, dy, lddy, dx, lddx, rows, D, eps, part);
+    OV_LAUNCH_CHECK();
+    // part[w][0][:] = dgamma partial, part[w][1][:] = dbeta partial of wave w: two strided column sums
+    hipLaunchKernelGGL(rows_sum, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, st, part, blocks * 4, D, (int64_t)2 * D, dgamma);
+    OV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(rows_sum, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, st, part + D, blocks * 4, D, (int64_t)2 * D, dbeta);
+    OV_LAUNCH_CHECK();
+    return OV_OK;
+}
+
+extern "C" int ov_gelu_backward(const ov_bf16* a, int64_t lda, const ov_bf16* dh, int64_t lddh, ov_bf16* da, int64_t ldda, int64_t rows,
+                                int N, int tanh_form, ov_stream_t stream) {
+    if (!a || !dh || !da || rows <= 0 || N <= 0) return OV_ERR_INVALID;
+    if (N % 8 || lda % 8 || lddh % 8 || ldda % 8 || lda < N || lddh < N || ldda < N) return OV_ERR_UNSUPPORTED;
+    if (((uintptr_t)a | (uintptr_t)dh | (uintptr_t)da) & 15) return OV_ERR_INVALID;
+    const int64_t total = rows * (N / 8);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipStream_t st = (hipStream_t)stream;
+    if (tanh_form) hipLaunchKernelGGL(gelu_bwd<true>, dim3((unsigned)blocks), dim3(256), 0, st, a, lda, dh, lddh, da, ldda, rows, N / 8);
+    else hipLaunchKernelGGL(gelu_bwd<false>, dim3((unsigned)blocks), dim3(256), 0, st, a, lda, dh, lddh, da, ldda, rows, N / 8);
+    OV_LAUNCH_CHECK();
+    return OV_OK;
+}

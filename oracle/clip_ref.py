@@ -46,6 +46,40 @@ def gelu(x: torch.Tensor, tanh: bool) -> torch.Tensor:
     return F.gelu(x, approximate="tanh" if tanh else "none")
 
 
+def layer_norm_backward(x, w, dy, eps: float = LN_EPS):
+    """What autograd returns for transformer.py:24-30 (F.layer_norm, biased variance), in closed form, fp32:
+    dx = rstd (q - mean(q) - xhat mean(q xhat)) with q = dy * w;  dw = sum_rows dy * xhat;  db = sum_rows dy."""
+    x, w, dy = x.float(), w.float(), dy.float()
+    mean = x.mean(-1, keepdim=True)
+    rstd = torch.rsqrt(((x - mean) ** 2).mean(-1, keepdim=True) + eps)
+    xh = (x - mean) * rstd
+    q = dy * w
+    dx = rstd * (q - q.mean(-1, keepdim=True) - xh * (q * xh).mean(-1, keepdim=True))
+    flat = lambda t: t.reshape(-1, t.shape[-1])
+    return dx, (flat(dy) * flat(xh)).sum(0), flat(dy).sum(0)
+
+
+def linear_backward(dy, x, w):
+    """nn.Linear y = x w^T + b (transformer.py:232-236 c_fc / c_proj; nn.MultiheadAttention's in/out projections):
+    dx = dy w, dw = dy^T x, db = sum_rows dy."""
+    dy, x, w = dy.float(), x.float(), w.float()
+    dy2, x2 = dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1])
+    return dy @ w, dy2.T @ x2, dy2.sum(0)
+
+
+def gelu_backward(a, dh, tanh: bool):
+    """d gelu(a) / d a * dh.  erf form: Phi(a) + a phi(a); tanh form: 0.5 (1 + t) + 0.5 a (1 - t^2) u', t = tanh(u),
+    u = sqrt(2/pi) (a + 0.044715 a^3)."""
+    a, dh = a.double(), dh.double()
+    if tanh:
+        c = math.sqrt(2.0 / math.pi)
+        t = torch.tanh(c * (a + 0.044715 * a ** 3))
+        g = 0.5 * (1 + t) + 0.5 * a * (1 - t * t) * c * (1 + 3 * 0.044715 * a * a)
+    else:
+        g = 0.5 * (1 + torch.erf(a / math.sqrt(2.0))) + a * torch.exp(-0.5 * a * a) / math.sqrt(2.0 * math.pi)
+    return (dh * g).float()
+
+
 def mha(x: torch.Tensor, in_w, in_b, out_w, out_b, heads: int) -> torch.Tensor:
     """Self-attention of nn.MultiheadAttention(batch_first=True), no mask, no dropout
     (transformer.py:225,239-252): packed qkv projection (order q,k,v), q scaled by hd^-0.5,

@@ -19,6 +19,7 @@ Files written (np.savez_compressed):
   large14_224.npz         L/14@224 + text-L, B=2: features (fp32 and the reference's bf16 mode), token slices
   small8_384.npz          S/8@384, B=1 (2305 tokens): features, token slices
   cliploss_ws.npz         ClipLoss(local_loss=True) per-rank losses at world_size 2 and 8 over gloo
+  opgrad.npz              autograd through the reference's LayerNorm / nn.Linear / nn.GELU for random upstream gradients
   cliploss_grad.npz       autograd gradients of ClipLoss at world_size 1 and per rank at world_size 2
 """
 from __future__ import annotations
@@ -332,6 +333,33 @@ def gen_lossgrad(lossmod, ref_root, out):
     np.savez_compressed(out, **res)
 
 
+def gen_opgrad(tr, out):
+    """autograd through the reference's own modules (transformer.py:24-30 LayerNorm; the block's nn.Linear and nn.GELU,
+    :232-236) for random upstream gradients: the pins of the operator-level backward restatements in oracle/clip_ref.py."""
+    g = torch.Generator().manual_seed(4321)
+    res = {}
+    x = (torch.randn(37, 192, generator=g) * 1.5 + 0.2).requires_grad_(True)
+    ln = tr.LayerNorm(192, eps=1e-6)
+    with torch.no_grad():
+        ln.weight.copy_(torch.randn(192, generator=g) * 0.1 + 1)
+        ln.bias.copy_(torch.randn(192, generator=g) * 0.1)
+    dy = torch.randn(37, 192, generator=g)
+    ln(x).backward(dy)
+    res.update(ln_x=f32(x), ln_w=f32(ln.weight), ln_dy=f32(dy), ln_dx=f32(x.grad), ln_dw=f32(ln.weight.grad), ln_db=f32(ln.bias.grad))
+    lin = torch.nn.Linear(128, 192)
+    xl = torch.randn(70, 128, generator=g).requires_grad_(True)
+    dyl = torch.randn(70, 192, generator=g)
+    lin(xl).backward(dyl)
+    res.update(lin_x=f32(xl), lin_w=f32(lin.weight), lin_dy=f32(dyl), lin_dx=f32(xl.grad), lin_dw=f32(lin.weight.grad),
+               lin_db=f32(lin.bias.grad))
+    for name, act in (("erf", torch.nn.GELU()), ("tanh", torch.nn.GELU(approximate="tanh"))):
+        a = torch.linspace(-6, 6, 385).requires_grad_(True)
+        dh = torch.randn(385, generator=g)
+        act(a).backward(dh)
+        res.update({f"gelu_{name}_a": f32(a), f"gelu_{name}_dh": f32(dh), f"gelu_{name}_da": f32(a.grad)})
+    np.savez_compressed(out, **res)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -348,6 +376,7 @@ def main():
         "small": lambda: gen_small(m, os.path.join(HERE, "small8_384.npz")),
         "cliploss": lambda: gen_cliploss(lossmod, a.ref, os.path.join(HERE, "cliploss_ws.npz")),
         "preprocess": lambda: gen_preprocess(a.ref, os.path.join(HERE, "preprocess.npz")),
+        "opgrad": lambda: gen_opgrad(tr, os.path.join(HERE, "opgrad.npz")),
         "lossgrad": lambda: gen_lossgrad(lossmod, a.ref, os.path.join(HERE, "cliploss_grad.npz")),
     }
     for k, fn in jobs.items():

@@ -141,3 +141,50 @@ def clip_loss_backward(img, txt, all_img, all_txt, scale, label_offset, terms, g
                                     float(grad), ptr(d_img), ptr(d_txt), ptr(d_ai) if gathered else None,
                                     ptr(d_at) if gathered else None, ptr(d_s), ptr(ws), nb, stream_ptr()), "ov_clip_loss_backward")
     return d_img, d_txt, d_ai, d_at, d_s
+
+
+def linear_backward(dy, x, w, want=("dx", "dw", "db")):
+    """ov_linear_backward for y = x w^T + b: returns (dX bf16 [M,K] | None, dW bf16 [N,K] | None, db fp32 [N] | None)."""
+    lib = _lib.load()
+    M, N = dy.shape
+    K = x.shape[1]
+    dx = torch.empty(M, K, dtype=torch.bfloat16, device=dy.device) if "dx" in want else None
+    dw = torch.empty(N, K, dtype=torch.bfloat16, device=dy.device) if "dw" in want else None
+    db = torch.empty(N, dtype=torch.float32, device=dy.device) if "db" in want else None
+    nb = lib.ov_linear_backward_workspace_bytes(M, N, K)
+    ws = torch.empty(nb + 256, dtype=torch.uint8, device=dy.device)
+    check(lib.ov_linear_backward(ptr(dy), dy.stride(0), ptr(x), x.stride(0), ptr(w), w.stride(0), M, N, K,
+                                 ptr(dx) if dx is not None else None, K, ptr(dw) if dw is not None else None, K,
+                                 ptr(db) if db is not None else None, ptr(ws), nb, stream_ptr()), "ov_linear_backward")
+    return dx, dw, db
+
+
+def transpose(x):
+    lib = _lib.load()
+    R, C = x.shape
+    rp = (R + 63) // 64 * 64
+    out = torch.full((C, rp), 7.0, dtype=torch.bfloat16, device=x.device)
+    check(lib.ov_transpose_bf16(ptr(x), x.stride(0), R, C, ptr(out), rp, stream_ptr()), "ov_transpose_bf16")
+    return out
+
+
+def layernorm_backward(x, gamma, dy, eps=1e-6):
+    lib = _lib.load()
+    rows, D = x.shape
+    dx = torch.empty_like(x)
+    dg = torch.empty(D, dtype=torch.float32, device=x.device)
+    db = torch.empty(D, dtype=torch.float32, device=x.device)
+    nb = lib.ov_layernorm_backward_workspace_bytes(rows, D)
+    ws = torch.empty(nb + 256, dtype=torch.uint8, device=x.device)
+    check(lib.ov_layernorm_backward(ptr(x), x.stride(0), ptr(gamma), ptr(dy), dy.stride(0), ptr(dx), dx.stride(0), ptr(dg), ptr(db),
+                                    rows, D, eps, ptr(ws), nb, stream_ptr()), "ov_layernorm_backward")
+    return dx, dg, db
+
+
+def gelu_backward(a, dh, tanh):
+    lib = _lib.load()
+    rows, N = a.shape
+    da = torch.empty_like(a)
+    check(lib.ov_gelu_backward(ptr(a), a.stride(0), ptr(dh), dh.stride(0), ptr(da), da.stride(0), rows, N, int(tanh), stream_ptr()),
+          "ov_gelu_backward")
+    return da

@@ -61,6 +61,13 @@ def test_argument_validation_of_the_widening_entry_points():
     # loss backward: null pointers are rejected; the workspace holds one partial per 32-row tile and direction
     assert lib.ov_clip_loss_backward(None, None, None, None, 16, 16, 192, 1.0, 0, None, 1.0, None, None, None, None, None, None, 0, None) == -1
     assert lib.ov_clip_loss_backward_workspace_bytes(256, 2048) >= 2 * 8 * 4
+    # operator-level backward: nulls and unsupported shapes are status codes
+    assert lib.ov_transpose_bf16(None, 8, 8, 8, None, 64, None) == -1
+    assert lib.ov_linear_backward(None, 64, None, 64, None, 64, 8, 64, 64, None, 64, None, 64, None, None, 0, None) == -1
+    assert lib.ov_layernorm_backward(None, 8, None, None, 8, None, 8, None, None, 1, 8, 1e-6, None, 0, None) == -1
+    assert lib.ov_gelu_backward(None, 8, None, 8, None, 8, 1, 8, 0, None) == -1
+    assert lib.ov_linear_backward_workspace_bytes(65792, 4096, 1024) >= 2 * 65792 * (4096 + 1024)
+    assert lib.ov_layernorm_backward_workspace_bytes(65792, 1024) > 0
     assert lib.ov_quant_rows_fp8(None, 1024, None, 1024, None, 4, 1024, None, None) == -1
     assert lib.ov_layernorm_quant_fp8(None, 1024, None, None, None, 1024, None, 4, 1024, 1e-6, None) == -1
     assert lib.ov_attention_fp8out(None, 192, None, 64, 1, 32, 1, 64, 0.125, None, None, None) == -1

@@ -266,6 +266,74 @@ def test_clip_loss_autograd_golden_world_size_2():
             assert dl < 1e-5 and di < 2e-6 and dt < 2e-6 and ds < 2e-6, (rank, tag, dl, di, dt, ds)
 
 
+def bf(t):
+    return t.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("R,C", [(1, 8), (64, 64), (257, 200), (1000, 1024), (65, 4096)])
+def test_transpose_bf16_exact(R, C):
+    x = bf(rnd(R, C, seed=40))
+    out = H.transpose(x.to(DEV)).cpu()
+    assert torch.equal(out[:, :R], x.T)                                 # a permutation of bytes: bit-exact
+    assert torch.count_nonzero(out[:, R:].float()) == 0                 # zero padding up to the GEMM's K granule
+
+
+@pytest.mark.parametrize("M,N,K", [(70, 192, 128), (514, 768, 192), (1285, 3072, 1024), (2056, 1024, 4096)])
+def test_linear_backward_vs_oracle(M, N, K):
+    """dX / dW bf16 outputs of fp32-accumulated products: one bf16 rounding (2^-9 relative) on top of the oracle evaluated on
+    the same bf16 inputs; db is an fp32 sum."""
+    dy, x, w = bf(rnd(M, N, seed=41)), bf(rnd(M, K, seed=42)), bf(rnd(N, K, seed=43) * K ** -0.5)
+    dx, dw, db = H.linear_backward(dy.to(DEV), x.to(DEV), w.to(DEV))
+    rdx, rdw, rdb = R.linear_backward(dy, x, w)
+    np.testing.assert_allclose(dx.float().cpu().numpy(), rdx.numpy(), rtol=1e-2, atol=2e-2 * float(rdx.abs().mean()))
+    np.testing.assert_allclose(dw.float().cpu().numpy(), rdw.numpy(), rtol=1e-2, atol=2e-2 * float(rdw.abs().mean()))
+    np.testing.assert_allclose(db.cpu().numpy(), rdb.numpy(), rtol=1e-5, atol=1e-4)
+    only = H.linear_backward(dy.to(DEV), x.to(DEV), w.to(DEV), want=("db",))
+    assert only[0] is None and only[1] is None and torch.equal(only[2], db)
+
+
+@pytest.mark.parametrize("rows,D", [(37, 192), (514, 768), (1285, 1024), (9, 1152), (5, 4096)])
+def test_layernorm_backward_vs_oracle(rows, D):
+    x, dy = bf(rnd(rows, D, seed=44) * 1.5 + 0.2), bf(rnd(rows, D, seed=45))
+    w = rnd(D, seed=46) * 0.1 + 1
+    dx, dg, db = H.layernorm_backward(x.to(DEV), w.to(DEV), dy.to(DEV))
+    rdx, rdg, rdb = R.layer_norm_backward(x, w, dy, 1e-6)
+    np.testing.assert_allclose(dx.float().cpu().numpy(), rdx.numpy(), rtol=1e-2, atol=1e-2)      # bf16 output
+    np.testing.assert_allclose(dg.cpu().numpy(), rdg.numpy(), rtol=1e-4, atol=1e-3)             # fp32 sums over rows
+    np.testing.assert_allclose(db.cpu().numpy(), rdb.numpy(), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("tanh", [False, True])
+def test_gelu_backward_vs_oracle_and_golden(tanh):
+    from conftest import golden
+    a, dh = bf(rnd(300, 1536, seed=47) * 2.0), bf(rnd(300, 1536, seed=48))
+    da = H.gelu_backward(a.to(DEV), dh.to(DEV), tanh).float().cpu()
+    ref = R.gelu_backward(a, dh, tanh)
+    np.testing.assert_allclose(da.numpy(), ref.numpy(), rtol=1e-2, atol=1e-3)                    # bf16 output; derivative error < 1e-6
+    g = golden("opgrad.npz")
+    name = "tanh" if tanh else "erf"
+    ga = torch.from_numpy(g[f"gelu_{name}_a"])[:384].reshape(1, 384)
+    one = torch.ones(1, 384)
+    d = H.gelu_backward(bf(ga).to(DEV), bf(one).to(DEV), tanh).float().cpu()
+    want = R.gelu_backward(bf(ga), one, tanh)
+    np.testing.assert_allclose(d.numpy(), want.numpy(), rtol=8e-3, atol=1e-3)
+
+
+def test_operator_backward_golden_reference():
+    """LayerNorm and Linear backward through the C ABI vs autograd through the reference's modules (opgrad.npz), on the
+    golden's inputs rounded to bf16 (the kernels' I/O type): tolerance = bf16 input and output rounding."""
+    from conftest import golden
+    g = {k: torch.from_numpy(v) for k, v in golden("opgrad.npz").items()}
+    dx, dg, db = H.layernorm_backward(bf(g["ln_x"]).to(DEV), g["ln_w"].to(DEV), bf(g["ln_dy"]).to(DEV))
+    np.testing.assert_allclose(dx.float().cpu().numpy(), g["ln_dx"].numpy(), rtol=3e-2, atol=3e-2)
+    np.testing.assert_allclose(dg.cpu().numpy(), g["ln_dw"].numpy(), rtol=3e-2, atol=8e-2)
+    np.testing.assert_allclose(db.cpu().numpy(), g["ln_db"].numpy(), rtol=3e-2, atol=8e-2)
+    dx, dw, db = H.linear_backward(bf(g["lin_dy"]).to(DEV), bf(g["lin_x"]).to(DEV), bf(g["lin_w"]).to(DEV))
+    np.testing.assert_allclose(dx.float().cpu().numpy(), g["lin_dx"].numpy(), rtol=3e-2, atol=3e-2)
+    np.testing.assert_allclose(dw.float().cpu().numpy(), g["lin_dw"].numpy(), rtol=3e-2, atol=2e-1)
+    np.testing.assert_allclose(db.cpu().numpy(), g["lin_db"].numpy(), rtol=3e-2, atol=1e-1)
+
+
 @pytest.mark.parametrize("M,N,K,epi", [(256, 256, 384, 0), (300, 520, 512, 0), (771, 3072, 1024, 1), (2048, 1024, 4096, 3),
                                        (65535, 1024, 1024, 0)])
 def test_gemm_fp8_matches_dequantised_fp32(M, N, K, epi):

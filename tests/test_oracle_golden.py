@@ -131,3 +131,15 @@ def test_oracle_loss_gradients_match_reference_autograd():
                 assert (got[r][0] - torch.from_numpy(g[tag + "_dimg"][r])).abs().max() < 2e-6, tag
                 assert (got[r][1] - torch.from_numpy(g[tag + "_dtxt"][r])).abs().max() < 2e-6, tag
                 assert abs(float(got[r][2]) - float(g[tag + "_dscale"][r])) < 2e-6, tag
+
+
+def test_oracle_operator_backward_matches_reference_autograd():
+    """Closed-form LayerNorm / Linear / GELU backward of the oracle vs autograd through the reference's modules (opgrad.npz)."""
+    g = {k: torch.from_numpy(v) for k, v in golden("opgrad.npz").items()}
+    dx, dw, db = R.layer_norm_backward(g["ln_x"], g["ln_w"], g["ln_dy"], 1e-6)
+    assert (dx - g["ln_dx"]).abs().max() < 5e-6 and (dw - g["ln_dw"]).abs().max() < 2e-5 and (db - g["ln_db"]).abs().max() < 2e-5
+    dx, dw, db = R.linear_backward(g["lin_dy"], g["lin_x"], g["lin_w"])
+    assert (dx - g["lin_dx"]).abs().max() < 2e-5 and (dw - g["lin_dw"]).abs().max() < 5e-5 and (db - g["lin_db"]).abs().max() < 2e-5
+    for name, tanh in (("erf", False), ("tanh", True)):
+        da = R.gelu_backward(g[f"gelu_{name}_a"], g[f"gelu_{name}_dh"], tanh)
+        assert (da - g[f"gelu_{name}_da"]).abs().max() < 2e-6, name
