@@ -87,6 +87,12 @@ int ov_gemm(const ov_bf16* A, int64_t lda, const ov_bf16* W, int64_t ldw, const 
             const ov_bf16* R, int64_t ldr, int out_group, int resid_mod, int resid_off,
             ov_stream_t stream);
 
+/* `batch` independent products C_z = A_z W_z^T (bf16 out, no bias, no epilogue) in one launch; operand z = base + z * stride
+ * (elements).  With A_z / W_z = column ranges of one operand pair this is split-K with bf16 partials (ov_linear_backward's dW).
+ * Same shape rules as ov_gemm; strides % 8 == 0; batch <= 65535. */
+int ov_gemm_batched(const ov_bf16* A, int64_t lda, int64_t stride_a, const ov_bf16* W, int64_t ldw, int64_t stride_w, ov_bf16* C,
+                    int64_t ldc, int64_t stride_c, int64_t M, int N, int K, int batch, ov_stream_t stream);
+
 /* LayerNorm folded into the following Linear (LN(x) W^T + b without materialising LN(x)):
  *   C = epilogue( rstd[m] * (x W'^T - mean[m] * colsum[n]) + cvec[n] ),
  *   W'[n,k] = bf16(gamma[k] W[n,k]), colsum[n] = sum_k W'[n,k], cvec[n] = sum_k beta[k] W[n,k] + b[n]   (built once at pack time),

@@ -2,7 +2,7 @@
 //
 // The reference has no backward code of its own: it is torch autograd through nn.Linear / nn.LayerNorm / nn.GELU
 // (open_clip/transformer.py:15-30, 232-236).  What autograd computes for those modules is restated here:
-//   Linear     y = x W^T + b     ->  dx = dy W,  dW = dy^T x,  db = sum_rows dy
+//   Linear     y = x W^T + b     ->  dx = dy W,  dW = dy^T x (split over row ranges, bf16 partials, fp32 sum),  db = sum_rows dy
 //   LayerNorm  y = xhat g + b    ->  dx = rstd (q - mean(q) - xhat mean(q xhat)), q = dy g;  dg = sum dy xhat;  db = sum dy
 //   GELU       h = gelu(a)       ->  da = dh gelu'(a)     (exact erf for the vision tower, tanh form for the text tower)
 // The two Linear products run on the tuned forward GEMM (ov_gemm: C = A W^T with K contiguous on both operands), fed by
@@ -13,6 +13,8 @@
 extern "C" int ov_gemm(const ov_bf16* A, int64_t lda, const ov_bf16* W, int64_t ldw, const float* bias, ov_bf16* C, int64_t ldc,
                        int64_t M, int N, int K, int epilogue, const ov_bf16* R, int64_t ldr, int out_group, int resid_mod,
                        int resid_off, ov_stream_t stream);
+extern "C" int ov_gemm_batched(const ov_bf16* A, int64_t lda, int64_t stride_a, const ov_bf16* W, int64_t ldw, int64_t stride_w,
+                               ov_bf16* C, int64_t ldc, int64_t stride_c, int64_t M, int N, int K, int batch, ov_stream_t stream);
 
 namespace {
 
@@ -56,7 +58,15 @@ __global__ __launch_bounds__(256) void colsum_partial(const unsigned int* __rest
     const int64_t m0 = (int64_t)blockIdx.y * CS_ROWS;
     const int64_t m1 = m0 + CS_ROWS < M ? m0 + CS_ROWS : M;
     float s0 = 0.f, s1 = 0.f;
-    for (int64_t m = m0; m < m1; ++m) {
+    int64_t m = m0;
+    for (; m + 8 <= m1; m += 8) {
+        unsigned int w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) w[u] = x[(m + u) * ld2 + c2];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s0 += bf16lo_to_f32(w[u]); s1 += bf16hi_to_f32(w[u]); }
+    }
+    for (; m < m1; ++m) {
         const unsigned int w = x[m * ld2 + c2];
         s0 += bf16lo_to_f32(w);
         s1 += bf16hi_to_f32(w);
@@ -64,14 +74,67 @@ __global__ __launch_bounds__(256) void colsum_partial(const unsigned int* __rest
     float2* p = (float2*)(part + ((int64_t)blockIdx.y * N2 + c2) * 2);
     *p = make_float2(s0, s1);
 }
-// out[n] = sum over `nrow` partial rows (fixed order)
-__global__ __launch_bounds__(256) void rows_sum(const float* __restrict__ part, int64_t nrow, int N, int64_t stride,
+// out[split][n] = sum of partial rows [split * rows_per, (split + 1) * rows_per) (fixed order: wave w takes rows = w mod 4, eight
+// loads in flight, then the four waves are combined through LDS).  Block = 64 columns x 4 waves; grid (ceil(N / 64), nsplit).
+constexpr int RS_SPLIT = 32;
+__global__ __launch_bounds__(256) void rows_sum(const float* __restrict__ part, int64_t nrow, int N, int64_t stride, int64_t rows_per,
                                                 float* __restrict__ out) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + lane;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per;
+    const int64_t r1 = r0 + rows_per < nrow ? r0 + rows_per : nrow;
     float s = 0.f;
-    for (int64_t r = 0; r < nrow; ++r) s += part[r * stride + n];
-    out[n] = s;
+    if (n < N) {
+        int64_t r = r0 + wave;
+        for (; r + 28 < r1; r += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(r + 4 * u) * stride + n];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; r < r1; r += 4) s += part[r * stride + n];
+    }
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && n < N) out[(int64_t)blockIdx.y * N + n] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+}
+
+// column sums of `nrow` partial rows into out[N]; scratch = RS_SPLIT * N floats
+int launch_rows_sum(const float* part, int64_t nrow, int N, int64_t stride, float* scratch, float* out, hipStream_t st) {
+    const unsigned gx = (unsigned)((N + 63) / 64);
+    if (nrow <= 4 * RS_SPLIT) {
+        hipLaunchKernelGGL(rows_sum, dim3(gx, 1), dim3(256), 0, st, part, nrow, N, stride, nrow, out);
+        OV_LAUNCH_CHECK();
+        return OV_OK;
+    }
+    const int64_t per = (nrow + RS_SPLIT - 1) / RS_SPLIT;
+    const int64_t nsplit = (nrow + per - 1) / per;
+    hipLaunchKernelGGL(rows_sum, dim3(gx, (unsigned)nsplit), dim3(256), 0, st, part, nrow, N, stride, per, scratch);
+    OV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(rows_sum, dim3(gx, 1), dim3(256), 0, st, (const float*)scratch, nsplit, N, (int64_t)N, nsplit, out);
+    OV_LAUNCH_CHECK();
+    return OV_OK;
+}
+
+// out = bf16( sum_z fp32(part[z]) ) over `nz` split-K partials of `total8` 8-element groups each (fixed order)
+__global__ __launch_bounds__(256) void splitk_sum(const ov_bf16* __restrict__ part, int64_t stride, int nz, int64_t total8, int K8,
+                                                  ov_bf16* __restrict__ out, int64_t ldo) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total8; i += (int64_t)gridDim.x * 256) {
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        for (int z = 0; z < nz; ++z) {
+            const u32x4_t w = *(const u32x4_t*)(part + z * stride + i * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc[2 * e] += bf16lo_to_f32(w[e]); acc[2 * e + 1] += bf16hi_to_f32(w[e]); }
+        }
+        const int64_t r = i / K8;
+        const int c = (int)(i - r * K8) * 8;
+        const u32x4_t o = {pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]), pack_bf16x2(acc[4], acc[5]), pack_bf16x2(acc[6], acc[7])};
+        *(u32x4_t*)(out + r * ldo + c) = o;
+    }
 }
 
 // LayerNorm backward, wave per row (row in registers, like the forward).  dgamma / dbeta partial sums stay in the wave's
@@ -209,8 +272,26 @@ __global__ __launch_bounds__(256) void gelu_bwd(const ov_bf16* __restrict__ a, i
 inline int64_t pad64(int64_t v) { return (v + 63) / 64 * 64; }
 inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 
-int launch_transpose(const ov_bf16* in, int64_t ld_in, int64_t R, int C, ov_bf16* out, int64_t ld_out, hipStream_t st) {
-    const dim3 grid((unsigned)(pad64(R) / 64), (unsigned)((C + 63) / 64));
+// split-K plan of dW = dY^T X: the output has only (N / 256) (K / 256) tiles, so the M contraction is cut into `nz` ranges of
+// `chunk` rows (a multiple of 64) to put ~2 workgroups on every CU; rows past M are zeros written by the transposes
+struct SplitK { int nz; int64_t chunk, mp; };
+inline SplitK plan_splitk(int64_t M, int N, int K) {
+    const int64_t tiles = (int64_t)((N + 255) / 256) * ((K + 255) / 256);
+    int64_t nz = (512 + tiles - 1) / tiles;
+    if (nz > 32) nz = 32;
+    const int64_t max_nz = (M + 511) / 512;                       // at least 8 K-tiles per range
+    if (nz > max_nz) nz = max_nz;
+    if (nz < 1) nz = 1;
+    SplitK p;
+    p.chunk = pad64((M + nz - 1) / nz);
+    p.nz = (int)((M + p.chunk - 1) / p.chunk);
+    p.mp = p.chunk * p.nz;
+    return p;
+}
+
+// Rpad: multiple of 64 >= R; tiles past R are written as zeros
+int launch_transpose(const ov_bf16* in, int64_t ld_in, int64_t R, int64_t Rpad, int C, ov_bf16* out, int64_t ld_out, hipStream_t st) {
+    const dim3 grid((unsigned)(Rpad / 64), (unsigned)((C + 63) / 64));
     hipLaunchKernelGGL(transpose_bf16, grid, dim3(256), 0, st, (const unsigned short*)in, ld_in, R, C, (unsigned short*)out, ld_out);
     OV_LAUNCH_CHECK();
     return OV_OK;
@@ -224,14 +305,15 @@ extern "C" int ov_transpose_bf16(const ov_bf16* in, int64_t ld_in, int64_t rows,
     if (cols % 8 || ld_in % 8 || ld_out % 8 || ld_in < cols || ld_out < pad64(rows)) return OV_ERR_UNSUPPORTED;
     if (((uintptr_t)in | (uintptr_t)out) & 15) return OV_ERR_INVALID;
     if (pad64(rows) / 64 > 0x7fffffffLL) return OV_ERR_UNSUPPORTED;
-    return launch_transpose(in, ld_in, rows, cols, out, ld_out, (hipStream_t)stream);
+    return launch_transpose(in, ld_in, rows, pad64(rows), cols, out, ld_out, (hipStream_t)stream);
 }
 
 extern "C" size_t ov_linear_backward_workspace_bytes(int64_t M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
-    const int64_t mp = pad64(M);
-    return align256((size_t)K * N * 2) + align256((size_t)N * mp * 2) + align256((size_t)K * mp * 2) +
-           align256((size_t)((M + CS_ROWS - 1) / CS_ROWS) * N * 4);
+    const SplitK sp = plan_splitk(M, N, K);
+    return align256((size_t)K * N * 2) + align256((size_t)N * sp.mp * 2) + align256((size_t)K * sp.mp * 2) +
+           align256((size_t)sp.nz * N * K * 2) + align256((size_t)((M + CS_ROWS - 1) / CS_ROWS) * N * 4) +
+           align256((size_t)RS_SPLIT * N * 4);
 }
 
 extern "C" int ov_linear_backward(const ov_bf16* dY, int64_t lddy, const ov_bf16* X, int64_t ldx, const ov_bf16* W, int64_t ldw,
@@ -245,22 +327,35 @@ extern "C" int ov_linear_backward(const ov_bf16* dY, int64_t lddy, const ov_bf16
         return OV_ERR_INVALID;
     if (workspace_bytes < ov_linear_backward_workspace_bytes(M, N, K)) return OV_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    const int64_t mp = pad64(M);
+    const SplitK sp = plan_splitk(M, N, K);
+    const int64_t mp = sp.mp;
     char* ws = (char*)workspace;
     ov_bf16* Wt = (ov_bf16*)ws;  ws += align256((size_t)K * N * 2);          // [K, N]
     ov_bf16* dYt = (ov_bf16*)ws; ws += align256((size_t)N * mp * 2);         // [N, Mpad]
     ov_bf16* Xt = (ov_bf16*)ws;  ws += align256((size_t)K * mp * 2);         // [K, Mpad]
+    ov_bf16* dWp = (ov_bf16*)ws; ws += align256((size_t)sp.nz * N * K * 2); // [nz][N, K] split-K partials
     float* part = (float*)ws;
     int rc;
     if (dX) {       // dX[M, K] = dY[M, N] . W[N, K]  =  ov_gemm(A = dY, "W" = W^T [K, N]) contracting over N
-        if ((rc = launch_transpose(W, ldw, N, K, Wt, N, st)) != OV_OK) return rc;
+        if ((rc = launch_transpose(W, ldw, N, N, K, Wt, N, st)) != OV_OK) return rc;
         if ((rc = ov_gemm(dY, lddy, Wt, N, nullptr, dX, lddx, M, K, N, OV_EPI_BIAS, nullptr, 0, 0, 0, 0, stream)) != OV_OK) return rc;
     }
     if (dW) {       // dW[N, K] = dY^T[N, M] . X[M, K]  =  ov_gemm(A = dY^T [N, Mpad], "W" = X^T [K, Mpad]) contracting over Mpad (zeros past M)
-        if ((rc = launch_transpose(dY, lddy, M, N, dYt, mp, st)) != OV_OK) return rc;
-        if ((rc = launch_transpose(X, ldx, M, K, Xt, mp, st)) != OV_OK) return rc;
-        if (mp > 0x7fffffffLL) return OV_ERR_UNSUPPORTED;
-        if ((rc = ov_gemm(dYt, mp, Xt, mp, nullptr, dW, lddw, N, K, (int)mp, OV_EPI_BIAS, nullptr, 0, 0, 0, 0, stream)) != OV_OK) return rc;
+        if (sp.chunk > 0x7fffffffLL) return OV_ERR_UNSUPPORTED;
+        if ((rc = launch_transpose(dY, lddy, M, mp, N, dYt, mp, st)) != OV_OK) return rc;
+        if ((rc = launch_transpose(X, ldx, M, mp, K, Xt, mp, st)) != OV_OK) return rc;
+        if (sp.nz == 1) {
+            if ((rc = ov_gemm(dYt, mp, Xt, mp, nullptr, dW, lddw, N, K, (int)mp, OV_EPI_BIAS, nullptr, 0, 0, 0, 0, stream)) != OV_OK) return rc;
+        } else {     // range z contracts columns [z chunk, (z + 1) chunk) of both transposes into partial z; then one fp32 sum
+            if ((rc = ov_gemm_batched(dYt, mp, sp.chunk, Xt, mp, sp.chunk, dWp, K, (int64_t)N * K, N, K, (int)sp.chunk, sp.nz, stream)) != OV_OK)
+                return rc;
+            const int64_t total8 = (int64_t)N * K / 8;
+            int64_t blocks = (total8 + 255) / 256;
+            if (blocks > 4096) blocks = 4096;
+            hipLaunchKernelGGL(splitk_sum, dim3((unsigned)blocks), dim3(256), 0, st, (const ov_bf16*)dWp, (int64_t)N * K, sp.nz, total8, K / 8,
+                               dW, lddw);
+            OV_LAUNCH_CHECK();
+        }
     }
     if (db) {
         const int64_t nchunk = (M + CS_ROWS - 1) / CS_ROWS;
@@ -268,20 +363,20 @@ extern "C" int ov_linear_backward(const ov_bf16* dY, int64_t lddy, const ov_bf16
         hipLaunchKernelGGL(colsum_partial, dim3((unsigned)((N / 2 + 255) / 256), (unsigned)nchunk), dim3(256), 0, st,
                            (const unsigned int*)dY, lddy / 2, M, N / 2, part);
         OV_LAUNCH_CHECK();
-        hipLaunchKernelGGL(rows_sum, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, part, nchunk, N, (int64_t)N, db);
-        OV_LAUNCH_CHECK();
+        float* scratch = (float*)((char*)part + align256((size_t)nchunk * N * 4));
+        if ((rc = launch_rows_sum(part, nchunk, N, (int64_t)N, scratch, db, st)) != OV_OK) return rc;
     }
     return OV_OK;
 }
 
 namespace {
-constexpr int LNB_BLOCKS = 512;
+constexpr int LNB_BLOCKS = 1024;
 inline int64_t lnb_blocks(int64_t rows) { const int64_t b = (rows + 3) / 4; return b < LNB_BLOCKS ? b : LNB_BLOCKS; }
 }
 
 extern "C" size_t ov_layernorm_backward_workspace_bytes(int64_t rows, int D) {
     if (rows <= 0 || D <= 0) return 0;
-    return (size_t)lnb_blocks(rows) * 4 * 2 * D * sizeof(float);
+    return (size_t)lnb_blocks(rows) * 4 * 2 * D * sizeof(float) + (size_t)RS_SPLIT * D * sizeof(float);
 }
 
 extern "C" int ov_layernorm_backward(const ov_bf16* x, int64_t ldx, const float* gamma, const ov_bf16* dy, int64_t lddy, ov_bf16* dx,
@@ -303,11 +398,10 @@ extern "C" int ov_layernorm_backward(const ov_bf16* x, int64_t ldx, const float*
     else hipLaunchKernelGGL(layernorm_bwd_rows<8>, grid, blk, 0, st, x, ldx, gamma, dy, lddy, dx, lddx, rows, D, eps, part);
     OV_LAUNCH_CHECK();
     // part[w][0][:] = dgamma partial, part[w][1][:] = dbeta partial of wave w: two strided column sums
-    hipLaunchKernelGGL(rows_sum, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, st, part, blocks * 4, D, (int64_t)2 * D, dgamma);
-    OV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(rows_sum, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, st, part + D, blocks * 4, D, (int64_t)2 * D, dbeta);
-    OV_LAUNCH_CHECK();
-    return OV_OK;
+    float* scratch = part + (size_t)blocks * 4 * 2 * D;
+    int rc;
+    if ((rc = launch_rows_sum(part, blocks * 4, D, (int64_t)2 * D, scratch, dgamma, st)) != OV_OK) return rc;
+    return launch_rows_sum(part + D, blocks * 4, D, (int64_t)2 * D, scratch, dbeta, st);
 }
 
 extern "C" int ov_gelu_backward(const ov_bf16* a, int64_t lda, const ov_bf16* dh, int64_t lddh, ov_bf16* da, int64_t ldda, int64_t rows,

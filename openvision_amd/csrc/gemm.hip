@@ -35,6 +35,7 @@ struct GemmArgs {
     unsigned long long* stamps;     // diagnostics only (ov_debug_gemm_stamps): [block][tile slot][4] s_memtime values
     int stamp_slots;
     int ngroup;                     // persistent kernel: n-tiles per group of the XCD tile walk (== tiles_n: plain n-fastest walk)
+    int64_t batch_a, batch_w, batch_c;   // gemm_bf16_pp with gridDim.y > 1: element strides of A, W, C per batch entry (split-K partials)
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -232,8 +233,14 @@ constexpr int PIECE_BYTES = 256 * 64;          // 16 KiB
 __device__ __forceinline__ int swz4(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }
 
 template <int EPI>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp(const GemmArgs g) {
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp(const GemmArgs g_in) {
     __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
+    GemmArgs g = g_in;
+    if (gridDim.y > 1) {                        // batch entry (wave-uniform): independent operands and output per blockIdx.y
+        g.A += (int64_t)blockIdx.y * g.batch_a;
+        g.W += (int64_t)blockIdx.y * g.batch_w;
+        g.C += (int64_t)blockIdx.y * g.batch_c;
+    }
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -806,7 +813,7 @@ extern "C" int ov_gemm(const ov_bf16* A, int64_t lda, const ov_bf16* W, int64_t 
     const int64_t tiles_n = (N + BN - 1) / BN;
     if (tiles_m * tiles_n > 0x7fffffffLL || M > 0x7fff0000LL) return OV_ERR_UNSUPPORTED;    // 32-bit row indices in the kernels
     GemmArgs a{A, W, bias, C, R, lda, ldw, ldc, ldr, M, N, K, (int)tiles_m, (int)tiles_n,
-               out_group, resid_mod, resid_off, g_colsum, g_rowstats, g_stamps, g_stamp_slots, gemm_ngroup((int)tiles_m, (int)tiles_n, K)};
+               out_group, resid_mod, resid_off, g_colsum, g_rowstats, g_stamps, g_stamp_slots, gemm_ngroup((int)tiles_m, (int)tiles_n, K), 0, 0, 0};
     hipStream_t st = (hipStream_t)stream;
     switch (epilogue) {
         case OV_EPI_BIAS: return launch<OV_EPI_BIAS>(a, st);
@@ -815,6 +822,24 @@ extern "C" int ov_gemm(const ov_bf16* A, int64_t lda, const ov_bf16* W, int64_t 
         case OV_EPI_BIAS_RESIDUAL: return launch<OV_EPI_BIAS_RESIDUAL>(a, st);
         default: return OV_ERR_INVALID;
     }
+}
+
+// `batch` independent products C_z = A_z . W_z^T (bf16 out, no bias) in ONE launch of the non-persistent kernel, blockIdx.y = z.
+// With A_z / W_z = column ranges of one pair of operands this is split-K with bf16 partials (ov_linear_backward's dW).
+extern "C" int ov_gemm_batched(const ov_bf16* A, int64_t lda, int64_t stride_a, const ov_bf16* W, int64_t ldw, int64_t stride_w,
+                               ov_bf16* C, int64_t ldc, int64_t stride_c, int64_t M, int N, int K, int batch, ov_stream_t stream) {
+    if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0 || batch <= 0 || batch > 65535) return OV_ERR_INVALID;
+    if (K % BK || N % 8 || lda % 8 || ldw % 8 || ldc % 8 || stride_a % 8 || stride_w % 8 || stride_c % 8) return OV_ERR_UNSUPPORTED;
+    if (lda < K || ldw < K || ldc < N) return OV_ERR_INVALID;
+    if (((uintptr_t)A | (uintptr_t)W | (uintptr_t)C) & 15) return OV_ERR_INVALID;
+    const int64_t tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    if (tiles_m * tiles_n > 0x7fffffffLL || M > 0x7fff0000LL) return OV_ERR_UNSUPPORTED;
+    GemmArgs a{A, W, nullptr, C, nullptr, lda, ldw, ldc, 0, M, N, K, (int)tiles_m, (int)tiles_n, 0, 0, 0, nullptr, nullptr, nullptr, 0,
+               (int)tiles_n, stride_a, stride_w, stride_c};
+    hipLaunchKernelGGL(gemm_bf16_pp<OV_EPI_BIAS>, dim3((unsigned)(tiles_m * tiles_n), (unsigned)batch), dim3(NTHREADS), 0,
+                       (hipStream_t)stream, a);
+    OV_LAUNCH_CHECK();
+    return OV_OK;
 }
 
 // Diagnostics: when set, the persistent kernel's thread 0 of every workgroup records s_memtime at tile start / main-loop
