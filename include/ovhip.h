@@ -248,6 +248,13 @@ int ov_layernorm_backward(const ov_bf16* x, int64_t ldx, const float* gamma, con
                           float* dgamma, float* dbeta, int64_t rows, int D, float eps, void* workspace, size_t workspace_bytes,
                           ov_stream_t stream);
 
+/* Backward of ov_attention (unmasked softmax attention of nn.MultiheadAttention, transformer.py:225,239-252): from the packed
+ * qkv [B*L, 3*H*64], the forward output out [B*L, H*64] and the upstream gradient dout, writes dqkv [B*L, 3*H*64] = (dQ | dK | dV).
+ * The row log-sum-exp is recomputed (the forward keeps none).  head_dim 64 and L <= 288 (a head's Q, K, V, dO resident in LDS);
+ * OV_ERR_UNSUPPORTED otherwise.  Deterministic. */
+int ov_attention_backward(const ov_bf16* qkv, int64_t ld_qkv, const ov_bf16* out, int64_t ld_out, const ov_bf16* dout, int64_t ld_dout,
+                          ov_bf16* dqkv, int64_t ld_dqkv, int B, int L, int H, int hd, float scale, ov_stream_t stream);
+
 /* da = dh * gelu'(a) on the pre-activation a [rows, N] (tanh_form = 0: exact erf GELU, vision; 1: tanh form, text).  N % 8 == 0. */
 int ov_gelu_backward(const ov_bf16* a, int64_t lda, const ov_bf16* dh, int64_t lddh, ov_bf16* da, int64_t ldda, int64_t rows, int N,
                      int tanh_form, ov_stream_t stream);

@@ -1,0 +1,265 @@
+// attention_bwd.hip — backward of the unmasked softmax attention inside nn.MultiheadAttention (gfx950, head_dim 64).
+//
+// The reference obtains it from autograd through nn.MultiheadAttention (open_clip/transformer.py:225,239-252; torch
+// nn/functional.py scaled-dot-product path).  With S = scale Q K^T, P = softmax(S), O = P V and an upstream dO:
+//     dV = P^T dO,   dP = dO V^T,   dS = P * (dP - delta),  delta[q] = sum_d dO[q,d] O[q,d],   dQ = scale dS K,   dK = scale dS^T Q.
+// One workgroup per (image, head); Q, K, V and dO of the head live in LDS (L <= 288), every wave owns one 32-row tile:
+//   pass 1  (wave = query tile)  log-sum-exp of its rows (the forward does not keep it) and delta        -> LDS
+//   pass 2  (wave = query tile)  S^T, dP^T tiles against every key tile, dQ^T += K^T dS^T                -> dQ
+//   pass 3  (wave = key tile)    S, dP tiles against every query tile, dV^T += dO^T P, dK^T += Q^T dS   -> dK, dV
+// S and dP are recomputed in pass 3 (7 tile products per tile pair instead of the minimal 5) so that no accumulator is shared
+// between waves: no atomics, results are deterministic.  All products are v_mfma_f32_32x32x16_bf16; P and dS are rounded to bf16
+// for the second products exactly as the forward rounds P.  The LDS image of each tensor is [d half][row][32 d] (64-byte rows):
+// it serves both the row-major 16-byte fragment reads (contraction over d) and ds_read_b64_tr_b16 (contraction over rows).
+// First version: correct and deterministic, not yet tuned (plain staging, no swizzle on the row-major reads).
+#include "common.h"
+
+namespace {
+
+struct AttnBwdArgs {
+    const ov_bf16* qkv; int64_t ldq;          // [B*L, 3*H*64]  (q | k | v)
+    const ov_bf16* out; int64_t ldo;          // forward output [B*L, H*64]
+    const ov_bf16* dout; int64_t lddo;        // upstream gradient [B*L, H*64]
+    ov_bf16* dqkv; int64_t lddq;              // [B*L, 3*H*64]  (dq | dk | dv)
+    int L, H, KC;
+    float scale, scale_log2;
+};
+
+__device__ __forceinline__ bf16x8_t join8(u32x2_t a, u32x2_t b) {
+    const u32x4_t w = {a[0], a[1], b[0], b[1]};
+    return __builtin_bit_cast(bf16x8_t, w);
+}
+// A-operand fragment of X^T for one 16-row contraction step: rows addr.. and 8 rows further (offset 512 B), transposed by the
+// LDS unit.  Read and wait in ONE asm statement: the destination registers are complete when the statement ends.
+__device__ __forceinline__ bf16x8_t tr_frag(unsigned addr) {
+    u32x2_t a, b;
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:512\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(a), "=&v"(b) : "v"(addr) : "memory");
+    return join8(a, b);
+}
+__device__ __forceinline__ bf16x8_t pack8(const f32x16_t& t, int s) {
+    const u32x4_t w = {pack_bf16x2(t[8 * s + 0], t[8 * s + 1]), pack_bf16x2(t[8 * s + 2], t[8 * s + 3]),
+                       pack_bf16x2(t[8 * s + 4], t[8 * s + 5]), pack_bf16x2(t[8 * s + 6], t[8 * s + 7])};
+    return __builtin_bit_cast(bf16x8_t, w);
+}
+__device__ __forceinline__ float swap_halves(float v) { return __shfl_xor(v, 32, 64); }
+
+__global__ __launch_bounds__(640) void attn_bwd_hd64(const AttnBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h2 = lane >> 5;
+    const int L = a.L, KC = a.KC, HD = a.H * 64;
+    const int b = blockIdx.x / a.H, h = blockIdx.x - b * a.H;
+    const int img_bytes = KC * 128;
+    char* qimg = smem;
+    char* kimg = smem + img_bytes;
+    char* vimg = smem + 2 * img_bytes;
+    char* dimg = smem + 3 * img_bytes;
+    float* lse = (float*)(smem + 4 * img_bytes);
+    float* dlt = lse + KC;
+
+    // ---- stage the four [KC, 64] tiles of this head: piece p of an image = (d half, row, 16-byte chunk)
+    {
+        const int npiece = KC * 8;
+        const ov_bf16* qbase = a.qkv + (int64_t)b * L * a.ldq + h * 64;
+        const ov_bf16* dbase = a.dout + (int64_t)b * L * a.lddo + h * 64;
+        for (int q = tid; q < 4 * npiece; q += blockDim.x) {
+            const int t = q / npiece, p = q - t * npiece;
+            const int dh = p / (KC * 4), pp = p - dh * KC * 4;
+            int row = pp >> 2;
+            row = row < L ? row : L - 1;
+            const int col = (dh * 4 + (pp & 3)) * 8;
+            const ov_bf16* src = t < 3 ? qbase + (int64_t)row * a.ldq + t * HD + col : dbase + (int64_t)row * a.lddo + col;
+            *(u32x4_t*)(smem + t * img_bytes + p * 16) = *(const u32x4_t*)src;
+        }
+    }
+    __syncthreads();
+
+    // row-major fragment (contraction over d): row = tile * 32 + r, d = 16 st + 8 h2 .. + 8
+    auto frag = [&](const char* img, int tile, int st) {
+        return *(const bf16x8_t*)(img + (st >> 1) * KC * 64 + (tile * 32 + r) * 64 + ((st & 1) * 16 + 8 * h2) * 2);
+    };
+    const int vi = lane & 15, vg = (lane >> 4) & 1;
+    const unsigned tr_lane = (unsigned)((4 * h2 + (vi >> 2)) * 64 + (16 * vg + 4 * (vi & 3)) * 2);
+    auto tr_addr = [&](const char* img, int tile, int dh, int s) {
+        return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)img + (unsigned)(dh * KC * 64 + tile * 2048 + s * 1024) + tr_lane;
+    };
+    const int nt = KC >> 5;                       // tiles = waves
+
+    // ================= passes 1 and 2: this wave's QUERY tile =================
+    {
+        const int i = wave;
+        const int query = i * 32 + r;
+        bf16x8_t qB[4], dB[4];
+#pragma unroll
+        for (int st = 0; st < 4; ++st) { qB[st] = frag(qimg, i, st); dB[st] = frag(dimg, i, st); }
+        // pass 1: lse (log2 units) of row `query`; a lane sees the keys (t&3) + 8 (t>>2) + 4 h2 of each tile
+        float m = -INFINITY, l = 0.f;
+        for (int j = 0; j < nt; ++j) {
+            f32x16_t s;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) s[t] = 0.f;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(kimg, j, st), qB[st], s, 0, 0, 0);
+            float mx = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int key = j * 32 + (t & 3) + 8 * (t >> 2) + 4 * h2;
+                s[t] = key < L ? s[t] * a.scale_log2 : -INFINITY;
+                mx = fmaxf(mx, s[t]);
+            }
+            if (mx > -INFINITY) {
+                const float mn = fmaxf(m, mx);
+                float ps = 0.f;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) ps += __builtin_amdgcn_exp2f(s[t] - mn);
+                l = l * (m > -INFINITY ? __builtin_amdgcn_exp2f(m - mn) : 0.f) + ps;
+                m = mn;
+            }
+        }
+        {
+            const float mo = swap_halves(m), lo = swap_halves(l);
+            const float mn = fmaxf(m, mo);                       // finite: key 0 is always valid for one of the halves
+            l = l * (m > -INFINITY ? __builtin_amdgcn_exp2f(m - mn) : 0.f) + lo * (mo > -INFINITY ? __builtin_amdgcn_exp2f(mo - mn) : 0.f);
+            m = mn;
+        }
+        const float lse2 = m + __builtin_amdgcn_logf(l);         // v_log_f32 = log2
+        // delta = sum_d dO[q, d] O[q, d]: this lane takes d half h2
+        float delta = 0.f;
+        {
+            const int qrow = query < L ? query : L - 1;
+            const ov_bf16* op = a.out + ((int64_t)b * L + qrow) * a.ldo + h * 64 + 32 * h2;
+            const char* dp = dimg + h2 * KC * 64 + query * 64;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const u32x4_t ov = *(const u32x4_t*)(op + 8 * c);
+                const u32x4_t dv = *(const u32x4_t*)(dp + 16 * c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    delta = fmaf(bf16lo_to_f32(ov[e]), bf16lo_to_f32(dv[e]), delta);
+                    delta = fmaf(bf16hi_to_f32(ov[e]), bf16hi_to_f32(dv[e]), delta);
+                }
+            }
+            delta += swap_halves(delta);
+        }
+        if (h2 == 0) { lse[query] = lse2; dlt[query] = delta; }
+
+        // pass 2: dQ^T[d, query] += K_j^T[d, key] dS^T[key, query]
+        f32x16_t dq0, dq1;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) { dq0[t] = 0.f; dq1[t] = 0.f; }
+        for (int j = 0; j < nt; ++j) {
+            f32x16_t s, dp;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) { s[t] = 0.f; dp[t] = 0.f; }
+#pragma unroll
+            for (int st = 0; st < 4; ++st) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(kimg, j, st), qB[st], s, 0, 0, 0);
+#pragma unroll
+            for (int st = 0; st < 4; ++st) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(vimg, j, st), dB[st], dp, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int key = j * 32 + (t & 3) + 8 * (t >> 2) + 4 * h2;
+                const float p = key < L ? __builtin_amdgcn_exp2f(fmaf(s[t], a.scale_log2, -lse2)) : 0.f;
+                s[t] = p * (dp[t] - delta);                      // dS^T
+            }
+            const bf16x8_t b0 = pack8(s, 0), b1 = pack8(s, 1);
+            dq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(tr_addr(kimg, j, 0, 0)), b0, dq0, 0, 0, 0);
+            dq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(tr_addr(kimg, j, 1, 0)), b0, dq1, 0, 0, 0);
+            dq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(tr_addr(kimg, j, 0, 1)), b1, dq0, 0, 0, 0);
+            dq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(tr_addr(kimg, j, 1, 1)), b1, dq1, 0, 0, 0);
+        }
+        if (query < L) {                                         // rows d = 8 g + 4 h2 + e (dq0), + 32 (dq1)
+            ov_bf16* op = a.dqkv + ((int64_t)b * L + query) * a.lddq + h * 64 + 4 * h2;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const u32x2_t w0 = {pack_bf16x2(dq0[4 * g] * a.scale, dq0[4 * g + 1] * a.scale), pack_bf16x2(dq0[4 * g + 2] * a.scale, dq0[4 * g + 3] * a.scale)};
+                const u32x2_t w1 = {pack_bf16x2(dq1[4 * g] * a.scale, dq1[4 * g + 1] * a.scale), pack_bf16x2(dq1[4 * g + 2] * a.scale, dq1[4 * g + 3] * a.scale)};
+                *(u32x2_t*)(op + 8 * g) = w0;
+                *(u32x2_t*)(op + 32 + 8 * g) = w1;
+            }
+        }
+    }
+    __syncthreads();                                             // every row's lse / delta is in LDS
+
+    // ================= pass 3: this wave's KEY tile =================
+    {
+        const int j = wave;
+        const int key = j * 32 + r;
+        bf16x8_t kB[4], vB[4];
+#pragma unroll
+        for (int st = 0; st < 4; ++st) { kB[st] = frag(kimg, j, st); vB[st] = frag(vimg, j, st); }
+        f32x16_t dk0, dk1, dv0, dv1;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) { dk0[t] = 0.f; dk1[t] = 0.f; dv0[t] = 0.f; dv1[t] = 0.f; }
+        for (int i = 0; i < nt; ++i) {
+            f32x16_t s, dp;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) { s[t] = 0.f; dp[t] = 0.f; }
+#pragma unroll
+            for (int st = 0; st < 4; ++st) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(qimg, i, st), kB[st], s, 0, 0, 0);
+#pragma unroll
+            for (int st = 0; st < 4; ++st) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(dimg, i, st), vB[st], dp, 0, 0, 0);
+            // s[t], dp[t]: query i*32 + (t&3) + 8 (t>>2) + 4 h2 (register), key = lane column
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int q = i * 32 + (t & 3) + 8 * (t >> 2) + 4 * h2;
+                const float p = q < L ? __builtin_amdgcn_exp2f(fmaf(s[t], a.scale_log2, -lse[q])) : 0.f;
+                s[t] = p;                                        // P
+                dp[t] = p * (dp[t] - dlt[q]);                    // dS
+            }
+            const bf16x8_t p0 = pack8(s, 0), p1 = pack8(s, 1), g0 = pack8(dp, 0), g1 = pack8(dp, 1);
+            dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(tr_addr(dimg, i, 0, 0)), p0, dv0, 0, 0, 0);
+            dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(tr_addr(dimg, i, 1, 0)), p0, dv1, 0, 0, 0);
+            dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(tr_addr(dimg, i, 0, 1)), p1, dv0, 0, 0, 0);
+            dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(tr_addr(dimg, i, 1, 1)), p1, dv1, 0, 0, 0);
+            dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(tr_addr(qimg, i, 0, 0)), g0, dk0, 0, 0, 0);
+            dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(tr_addr(qimg, i, 1, 0)), g0, dk1, 0, 0, 0);
+            dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(tr_addr(qimg, i, 0, 1)), g1, dk0, 0, 0, 0);
+            dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(tr_addr(qimg, i, 1, 1)), g1, dk1, 0, 0, 0);
+        }
+        if (key < L) {
+            ov_bf16* kp = a.dqkv + ((int64_t)b * L + key) * a.lddq + HD + h * 64 + 4 * h2;
+            ov_bf16* vp = kp + HD;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const u32x2_t k0 = {pack_bf16x2(dk0[4 * g] * a.scale, dk0[4 * g + 1] * a.scale), pack_bf16x2(dk0[4 * g + 2] * a.scale, dk0[4 * g + 3] * a.scale)};
+                const u32x2_t k1 = {pack_bf16x2(dk1[4 * g] * a.scale, dk1[4 * g + 1] * a.scale), pack_bf16x2(dk1[4 * g + 2] * a.scale, dk1[4 * g + 3] * a.scale)};
+                const u32x2_t v0 = {pack_bf16x2(dv0[4 * g], dv0[4 * g + 1]), pack_bf16x2(dv0[4 * g + 2], dv0[4 * g + 3])};
+                const u32x2_t v1 = {pack_bf16x2(dv1[4 * g], dv1[4 * g + 1]), pack_bf16x2(dv1[4 * g + 2], dv1[4 * g + 3])};
+                *(u32x2_t*)(kp + 8 * g) = k0;
+                *(u32x2_t*)(kp + 32 + 8 * g) = k1;
+                *(u32x2_t*)(vp + 8 * g) = v0;
+                *(u32x2_t*)(vp + 32 + 8 * g) = v1;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int ov_attention_backward(const ov_bf16* qkv, int64_t ld_qkv, const ov_bf16* out, int64_t ld_out, const ov_bf16* dout,
+                                     int64_t ld_dout, ov_bf16* dqkv, int64_t ld_dqkv, int B, int L, int H, int hd, float scale,
+                                     ov_stream_t stream) {
+    if (!qkv || !out || !dout || !dqkv || B <= 0 || L <= 0 || H <= 0) return OV_ERR_INVALID;
+    if (hd != 64 || L > 288) return OV_ERR_UNSUPPORTED;          // K, V, Q, dO of a head resident in LDS
+    if (ld_qkv % 8 || ld_out % 8 || ld_dout % 8 || ld_dqkv % 8 || ld_qkv < 3 * H * 64 || ld_dqkv < 3 * H * 64 || ld_out < H * 64 ||
+        ld_dout < H * 64)
+        return OV_ERR_UNSUPPORTED;
+    if (((uintptr_t)qkv | (uintptr_t)out | (uintptr_t)dout | (uintptr_t)dqkv) & 15) return OV_ERR_INVALID;
+    if ((int64_t)B * H > 0x7fffffffLL) return OV_ERR_UNSUPPORTED;
+    AttnBwdArgs a;
+    a.qkv = qkv; a.ldq = ld_qkv; a.out = out; a.ldo = ld_out; a.dout = dout; a.lddo = ld_dout; a.dqkv = dqkv; a.lddq = ld_dqkv;
+    a.L = L; a.H = H; a.KC = (L + 31) / 32 * 32;
+    a.scale = scale; a.scale_log2 = scale * 1.4426950408889634f;
+    const size_t smem = (size_t)4 * a.KC * 128 + (size_t)2 * a.KC * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_hd64, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return ov_hip(e);
+        attr = true;
+    }
+    hipLaunchKernelGGL(attn_bwd_hd64, dim3((unsigned)(B * H)), dim3((unsigned)(a.KC / 32 * 64)), smem, (hipStream_t)stream, a);
+    OV_LAUNCH_CHECK();
+    return OV_OK;
+}

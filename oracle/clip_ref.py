@@ -80,6 +80,17 @@ def gelu_backward(a, dh, tanh: bool):
     return (dh * g).float()
 
 
+def attention_backward(q, k, v, do, scale: float):
+    """Backward of softmax(scale q k^T) v (the core of nn.MultiheadAttention, transformer.py:225,239-252) in closed form, fp32:
+    dv = p^T do, dp = do v^T, ds = p * (dp - rowsum(p * dp)), dq = scale ds k, dk = scale ds^T q.  Shapes [..., L, d]."""
+    q, k, v, do = q.float(), k.float(), v.float(), do.float()
+    p = torch.softmax(scale * q @ k.transpose(-1, -2), dim=-1)
+    dv = p.transpose(-1, -2) @ do
+    dp = do @ v.transpose(-1, -2)
+    ds = p * (dp - (p * dp).sum(-1, keepdim=True))
+    return scale * ds @ k, scale * ds.transpose(-1, -2) @ q, dv
+
+
 def mha(x: torch.Tensor, in_w, in_b, out_w, out_b, heads: int) -> torch.Tensor:
     """Self-attention of nn.MultiheadAttention(batch_first=True), no mask, no dropout
     (transformer.py:225,239-252): packed qkv projection (order q,k,v), q scaled by hd^-0.5,

@@ -352,6 +352,18 @@ def gen_opgrad(tr, out):
     lin(xl).backward(dyl)
     res.update(lin_x=f32(xl), lin_w=f32(lin.weight), lin_dy=f32(dyl), lin_dx=f32(xl.grad), lin_dw=f32(lin.weight.grad),
                lin_db=f32(lin.bias.grad))
+    # the block's attention module (transformer.py:225: nn.MultiheadAttention(d_model, n_head, batch_first=True)) with an identity
+    # out-projection and zero biases: d x = dq Wq + dk Wk + dv Wv isolates the softmax-attention backward
+    mha = torch.nn.MultiheadAttention(128, 2, batch_first=True)
+    with torch.no_grad():
+        mha.in_proj_weight.copy_(torch.randn(384, 128, generator=g) * 128 ** -0.5)
+        mha.in_proj_bias.zero_()
+        mha.out_proj.weight.copy_(torch.eye(128))
+        mha.out_proj.bias.zero_()
+    xa = torch.randn(2, 37, 128, generator=g).requires_grad_(True)
+    dya = torch.randn(2, 37, 128, generator=g)
+    mha(xa, xa, xa, need_weights=False)[0].backward(dya)
+    res.update(mha_x=f32(xa), mha_w=f32(mha.in_proj_weight), mha_dy=f32(dya), mha_dx=f32(xa.grad), mha_dw=f32(mha.in_proj_weight.grad))
     for name, act in (("erf", torch.nn.GELU()), ("tanh", torch.nn.GELU(approximate="tanh"))):
         a = torch.linspace(-6, 6, 385).requires_grad_(True)
         dh = torch.randn(385, generator=g)

@@ -188,3 +188,11 @@ def gelu_backward(a, dh, tanh):
     check(lib.ov_gelu_backward(ptr(a), a.stride(0), ptr(dh), dh.stride(0), ptr(da), da.stride(0), rows, N, int(tanh), stream_ptr()),
           "ov_gelu_backward")
     return da
+
+
+def attention_backward(qkv, out, dout, B, L, H, hd=64):
+    lib = _lib.load()
+    dqkv = torch.empty_like(qkv)
+    check(lib.ov_attention_backward(ptr(qkv), qkv.stride(0), ptr(out), out.stride(0), ptr(dout), dout.stride(0), ptr(dqkv), dqkv.stride(0),
+                                    B, L, H, hd, hd ** -0.5, stream_ptr()), "ov_attention_backward")
+    return dqkv

@@ -66,6 +66,8 @@ def test_argument_validation_of_the_widening_entry_points():
     assert lib.ov_linear_backward(None, 64, None, 64, None, 64, 8, 64, 64, None, 64, None, 64, None, None, 0, None) == -1
     assert lib.ov_layernorm_backward(None, 8, None, None, 8, None, 8, None, None, 1, 8, 1e-6, None, 0, None) == -1
     assert lib.ov_gelu_backward(None, 8, None, 8, None, 8, 1, 8, 0, None) == -1
+    assert lib.ov_attention_backward(None, 192, None, 64, None, 64, None, 192, 1, 8, 1, 64, 0.125, None) == -1
+    assert lib.ov_gemm_batched(None, 64, 64, None, 64, 64, None, 64, 64, 64, 64, 64, 2, None) == -1
     assert lib.ov_linear_backward_workspace_bytes(65792, 4096, 1024) >= 2 * 65792 * (4096 + 1024)
     assert lib.ov_layernorm_backward_workspace_bytes(65792, 1024) > 0
     assert lib.ov_quant_rows_fp8(None, 1024, None, 1024, None, 4, 1024, None, None) == -1

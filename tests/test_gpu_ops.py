@@ -11,6 +11,7 @@ import torch
 
 from oracle import clip_ref as R
 import hipops as H
+H_ = H          # the attention tests use H for the head count
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -317,6 +318,38 @@ def test_gelu_backward_vs_oracle_and_golden(tanh):
     d = H.gelu_backward(bf(ga).to(DEV), bf(one).to(DEV), tanh).float().cpu()
     want = R.gelu_backward(bf(ga), one, tanh)
     np.testing.assert_allclose(d.numpy(), want.numpy(), rtol=8e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("B,L,H", [(2, 257, 16), (3, 65, 2), (1, 33, 1), (2, 80, 12), (1, 288, 1), (2, 5, 1), (1, 1, 1), (2, 101, 3)])
+def test_attention_backward_vs_oracle(B, L, H):
+    """dQ | dK | dV of the softmax attention vs the oracle's closed form on the same bf16 inputs.  P and dS are rounded to bf16 for
+    the second products (as the forward rounds P) and the outputs are bf16: 2e-2 relative of the gradient scale."""
+    qkv = bf(rnd(B * L, 3 * H * 64, seed=50))
+    dout = bf(rnd(B * L, H * 64, seed=51))
+    out = H_.attention(qkv.to(DEV), B, L, H)
+    dqkv = H_.attention_backward(qkv.to(DEV), out, dout.to(DEV), B, L, H).float().cpu()
+    q, k, v = [t.view(B, L, H, 64).transpose(1, 2) for t in qkv.float().view(B, L, 3 * H * 64).split(H * 64, dim=-1)]
+    do = dout.float().view(B, L, H, 64).transpose(1, 2)
+    ref = torch.cat([t.transpose(1, 2).reshape(B * L, H * 64) for t in R.attention_backward(q, k, v, do, 0.125)], dim=-1)
+    for name, sl in (("dq", slice(0, H * 64)), ("dk", slice(H * 64, 2 * H * 64)), ("dv", slice(2 * H * 64, 3 * H * 64))):
+        got, want = dqkv[:, sl], ref[:, sl]
+        tol = 2e-2 * float(want.abs().max()) + 1e-3
+        assert float((got - want).abs().max()) < tol, (name, float((got - want).abs().max()), tol)
+    again = H_.attention_backward(qkv.to(DEV), out, dout.to(DEV), B, L, H).float().cpu()
+    assert torch.equal(again, dqkv)                                       # deterministic
+
+
+def test_attention_backward_golden_reference():
+    """Through the reference block's attention module (opgrad.npz): d x = dqkv W_in with an identity out-projection."""
+    from conftest import golden
+    g = {k: torch.from_numpy(v) for k, v in golden("opgrad.npz").items()}
+    x, w, dy = g["mha_x"], g["mha_w"], g["mha_dy"]
+    B, L, D = x.shape
+    qkv = bf((x @ w.T).reshape(B * L, 3 * D))
+    out = H_.attention(qkv.to(DEV), B, L, 2)
+    dqkv = H_.attention_backward(qkv.to(DEV), out, bf(dy.reshape(B * L, D)).to(DEV), B, L, 2).float().cpu()
+    dx = (dqkv @ w).view(B, L, D)
+    assert float((dx - g["mha_dx"]).abs().max()) < 3e-2 * float(g["mha_dx"].abs().max()) + 2e-3
 
 
 def test_operator_backward_golden_reference():

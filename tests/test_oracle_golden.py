@@ -143,3 +143,19 @@ def test_oracle_operator_backward_matches_reference_autograd():
     for name, tanh in (("erf", False), ("tanh", True)):
         da = R.gelu_backward(g[f"gelu_{name}_a"], g[f"gelu_{name}_dh"], tanh)
         assert (da - g[f"gelu_{name}_da"]).abs().max() < 2e-6, name
+
+
+def test_oracle_attention_backward_matches_reference_autograd():
+    """oracle.attention_backward vs autograd through nn.MultiheadAttention as the reference block builds it (opgrad.npz, identity
+    out-projection): d x = dq Wq + dk Wk + dv Wv and d W_in = [dq; dk; dv]^T x."""
+    g = {k: torch.from_numpy(v) for k, v in golden("opgrad.npz").items()}
+    x, w, dy = g["mha_x"], g["mha_w"], g["mha_dy"]
+    B, L, D = x.shape
+    H = 2
+    qkv = x @ w.T
+    q, k, v = [t.view(B, L, H, 64).transpose(1, 2) for t in qkv.split(D, dim=-1)]
+    do = dy.view(B, L, H, 64).transpose(1, 2)
+    dq, dk, dv = R.attention_backward(q, k, v, do, 64 ** -0.5)
+    dqkv = torch.cat([t.transpose(1, 2).reshape(B, L, D) for t in (dq, dk, dv)], dim=-1)
+    assert (dqkv @ w - g["mha_dx"]).abs().max() < 2e-5
+    assert (dqkv.reshape(-1, 3 * D).T @ x.reshape(-1, D) - g["mha_dw"]).abs().max() < 5e-5

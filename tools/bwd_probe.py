@@ -32,3 +32,8 @@ a = torch.randn(M, 4096, device="cuda").to(torch.bfloat16); dh = torch.randn(M, 
 for tanh in (False, True):
     ms = timeit(lambda: H.gelu_backward(a, dh, tanh))
     print(f"gelu_backward tanh={tanh} [{M} x 4096]: {ms:.3f} ms = {3 * M * 4096 * 2 / ms / 1e6:.0f} GB/s")
+B, L, Hh = 256, 257, 16
+qkv = torch.randn(B * L, 3 * Hh * 64, device="cuda").to(torch.bfloat16); dout = torch.randn(B * L, Hh * 64, device="cuda").to(torch.bfloat16)
+out = H.attention(qkv, B, L, Hh)
+ms = timeit(lambda: H.attention_backward(qkv, out, dout, B, L, Hh))
+print(f"attention_backward B {B} L {L} H {Hh}: {ms:.3f} ms = {10.0 * B * Hh * L * L * 64 / ms / 1e9:.0f} TFLOP/s (minimal 5 products; forward: 4 L^2 64 per head)")
