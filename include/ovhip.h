@@ -234,7 +234,7 @@ int ov_clip_loss_backward(const float* img, const float* txt, const float* all_i
 int ov_transpose_bf16(const ov_bf16* in, int64_t ld_in, int64_t rows, int cols, ov_bf16* out, int64_t ld_out, ov_stream_t stream);
 
 /* y = x W^T + b  (x [M, K], W [N, K], dY [M, N]):  dX = dY W  [M, K],  dW = dY^T x  [N, K] (bf16),  db = column sums of dY (fp32 [N]).
- * Any of dX / dW / db may be NULL (skipped).  N % 64 == 0, K % 64 == 0.  Both products run on ov_gemm, fed by LDS-staged transposes
+ * Any of dX / dW / db may be NULL (skipped; x is only read for dW).  N % 64 == 0, K % 64 == 0.  Both products run on ov_gemm, fed by LDS-staged transposes
  * held in the workspace (ov_linear_backward_workspace_bytes). */
 size_t ov_linear_backward_workspace_bytes(int64_t M, int N, int K);
 int ov_linear_backward(const ov_bf16* dY, int64_t lddy, const ov_bf16* X, int64_t ldx, const ov_bf16* W, int64_t ldw, int64_t M, int N,
@@ -244,9 +244,10 @@ int ov_linear_backward(const ov_bf16* dY, int64_t lddy, const ov_bf16* X, int64_
 /* Backward of ov_layernorm on bf16 rows: dx = rstd (q - mean(q) - xhat mean(q xhat)) with q = dy * gamma, dgamma = sum_rows dy * xhat,
  * dbeta = sum_rows dy (fp32 [D]).  D % 8 == 0, D <= 4096. */
 size_t ov_layernorm_backward_workspace_bytes(int64_t rows, int D);
-int ov_layernorm_backward(const ov_bf16* x, int64_t ldx, const float* gamma, const ov_bf16* dy, int64_t lddy, ov_bf16* dx, int64_t lddx,
-                          float* dgamma, float* dbeta, int64_t rows, int D, float eps, void* workspace, size_t workspace_bytes,
-                          ov_stream_t stream);
+int ov_layernorm_backward(const ov_bf16* x, int64_t ldx, const float* gamma, const ov_bf16* dy, int64_t lddy,
+                          const ov_bf16* dres /* optional: added to dx (the residual branch's gradient) */, int64_t lddres, ov_bf16* dx,
+                          int64_t lddx, float* dgamma, float* dbeta, int64_t rows, int D, float eps, void* workspace,
+                          size_t workspace_bytes, ov_stream_t stream);
 
 /* Backward of ov_attention (unmasked softmax attention of nn.MultiheadAttention, transformer.py:225,239-252): from the packed
  * qkv [B*L, 3*H*64], the forward output out [B*L, H*64] and the upstream gradient dout, writes dqkv [B*L, 3*H*64] = (dQ | dK | dV).
@@ -255,9 +256,10 @@ int ov_layernorm_backward(const ov_bf16* x, int64_t ldx, const float* gamma, con
 int ov_attention_backward(const ov_bf16* qkv, int64_t ld_qkv, const ov_bf16* out, int64_t ld_out, const ov_bf16* dout, int64_t ld_dout,
                           ov_bf16* dqkv, int64_t ld_dqkv, int B, int L, int H, int hd, float scale, ov_stream_t stream);
 
-/* da = dh * gelu'(a) on the pre-activation a [rows, N] (tanh_form = 0: exact erf GELU, vision; 1: tanh form, text).  N % 8 == 0. */
-int ov_gelu_backward(const ov_bf16* a, int64_t lda, const ov_bf16* dh, int64_t lddh, ov_bf16* da, int64_t ldda, int64_t rows, int N,
-                     int tanh_form, ov_stream_t stream);
+/* da = dh * gelu'(a) on the pre-activation a [rows, N] (tanh_form = 0: exact erf GELU, vision; 1: tanh form, text).  N % 8 == 0.
+ * h_out (optional) receives gelu(a).  da may alias dh and h_out may alias a (element-wise, in place). */
+int ov_gelu_backward(const ov_bf16* a, int64_t lda, const ov_bf16* dh, int64_t lddh, ov_bf16* da, int64_t ldda, ov_bf16* h_out,
+                     int64_t ldh, int64_t rows, int N, int tanh_form, ov_stream_t stream);
 
 /* ---- in-situ kernel timing (used by bench.py for the roofline object; off by default) ------------------
  * ov_profile_enable(mask, n): bracket every launch of the selected classes inside ov_tower_forward with a pair
@@ -327,6 +329,24 @@ size_t    ov_tower_workspace_bytes(const ov_tower* t, int B, int L);
 /* x[B*L, D] bf16 is updated in place through all `layers` blocks. */
 int       ov_tower_forward(const ov_tower* t, ov_bf16* x, int B, int L, void* workspace,
                            size_t workspace_bytes, ov_stream_t stream);
+
+/* ---- backward of one ResidualAttentionBlock (transformer.py:254-265 differentiated by autograd in the
+ * reference).  Activation recomputation: the caller keeps only the block INPUT x [B*L, D]; ln_1, qkv, attention, x1, ln_2 and the
+ * c_fc pre-activation are recomputed with the forward kernels, then ov_gelu_backward / ov_linear_backward / ov_layernorm_backward /
+ * ov_attention_backward run the chain rule.  `w` holds the module's own weights (no LN fold: qkv_colsum == fc_colsum == NULL,
+ * qkv_b / fc_b the module biases).  Gradients: weights bf16 [out, in] (same layout as the weights), biases and LN parameters fp32;
+ * all written (not accumulated).  dx may alias dy.  head_dim 64, mlp == mlp_pad, L <= 288; OV_ERR_UNSUPPORTED otherwise. */
+typedef struct {
+    float *ln1_w, *ln1_b;          /* [D] */
+    ov_bf16* qkv_w; float* qkv_b;  /* [3D, D], [3D] */
+    ov_bf16* out_w; float* out_b;  /* [D, D], [D] */
+    float *ln2_w, *ln2_b;          /* [D] */
+    ov_bf16* fc_w;  float* fc_b;   /* [mlp, D], [mlp] */
+    ov_bf16* proj_w; float* proj_b;/* [D, mlp], [D] */
+} ov_block_grads;
+size_t ov_block_backward_workspace_bytes(const ov_tower_cfg* cfg, int B, int L);
+int ov_block_backward(const ov_tower_cfg* cfg, const ov_block_weights* w, const ov_bf16* x, const ov_bf16* dy, ov_bf16* dx,
+                      const ov_block_grads* g, int B, int L, void* workspace, size_t workspace_bytes, ov_stream_t stream);
 
 typedef struct {      /* VisionTransformer front/back ends (OpenVision: no ln_pre, no conv bias) */
     int image_size, patch_size, kpad;              /* kpad = roundup(3*P*P, 64) */

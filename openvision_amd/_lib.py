@@ -28,6 +28,11 @@ class BlockWeights(C.Structure):
                                         "fc_w", "fc_b", "proj_w", "proj_b", "qkv_colsum", "fc_colsum")]
 
 
+class BlockGrads(C.Structure):
+    _fields_ = [(n, c_void_p) for n in ("ln1_w", "ln1_b", "qkv_w", "qkv_b", "out_w", "out_b", "ln2_w", "ln2_b", "fc_w", "fc_b",
+                                        "proj_w", "proj_b")]
+
+
 class BlockFp8(C.Structure):
     _fields_ = [(n, c_void_p) for n in ("qkv_w8", "qkv_s", "qkv_b", "out_w8", "out_s", "fc_w8", "fc_s", "fc_b", "proj_w8", "proj_s")]
 
@@ -94,9 +99,12 @@ SIGNATURES = {
     "ov_linear_backward": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_int64,
                                    c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     "ov_layernorm_backward_workspace_bytes": (c_size_t, [c_int64, c_int]),
-    "ov_layernorm_backward": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
-                                      c_int, c_float, c_void_p, c_size_t, c_void_p]),
-    "ov_gelu_backward": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
+    "ov_layernorm_backward": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
+                                      c_void_p, c_int64, c_int, c_float, c_void_p, c_size_t, c_void_p]),
+    "ov_gelu_backward": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int,
+                                 c_void_p]),
+    "ov_block_backward_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
+    "ov_block_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "ov_clip_loss_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p,
                                       c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "ov_profile_enable": (c_int, [C.c_uint, c_int]),

@@ -13,6 +13,13 @@
 extern "C" int ov_gemm(const ov_bf16* A, int64_t lda, const ov_bf16* W, int64_t ldw, const float* bias, ov_bf16* C, int64_t ldc,
                        int64_t M, int N, int K, int epilogue, const ov_bf16* R, int64_t ldr, int out_group, int resid_mod,
                        int resid_off, ov_stream_t stream);
+extern "C" int ov_layernorm(const void* x, int x_dtype, int64_t ldx, const float* gamma, const float* beta, void* y, int y_dtype,
+                            int64_t ldy, int64_t rows, int D, float eps, ov_stream_t stream);
+extern "C" int ov_attention(const ov_bf16* qkv, int64_t ld_qkv, ov_bf16* out, int64_t ld_out, int B, int L, int H, int hd, float scale,
+                            ov_stream_t stream);
+extern "C" int ov_attention_backward(const ov_bf16* qkv, int64_t ld_qkv, const ov_bf16* out, int64_t ld_out, const ov_bf16* dout,
+                                     int64_t ld_dout, ov_bf16* dqkv, int64_t ld_dqkv, int B, int L, int H, int hd, float scale,
+                                     ov_stream_t stream);
 extern "C" int ov_gemm_batched(const ov_bf16* A, int64_t lda, int64_t stride_a, const ov_bf16* W, int64_t ldw, int64_t stride_w,
                                ov_bf16* C, int64_t ldc, int64_t stride_c, int64_t M, int N, int K, int batch, ov_stream_t stream);
 
@@ -141,8 +148,9 @@ __global__ __launch_bounds__(256) void splitk_sum(const ov_bf16* __restrict__ pa
 // registers across the rows it owns and are written once: part[wave_global][2][D].
 template <int NCH>
 __global__ __launch_bounds__(256) void layernorm_bwd_rows(const ov_bf16* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
-                                                          const ov_bf16* __restrict__ dy, int64_t lddy, ov_bf16* __restrict__ dx,
-                                                          int64_t lddx, int64_t rows, int D, float eps, float* __restrict__ part) {
+                                                          const ov_bf16* __restrict__ dy, int64_t lddy, const ov_bf16* __restrict__ dres,
+                                                          int64_t lddres, ov_bf16* __restrict__ dx, int64_t lddx, int64_t rows, int D,
+                                                          float eps, float* __restrict__ part) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nchunk = D >> 3;
     const float invD = 1.0f / (float)D;
@@ -207,6 +215,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_rows(const ov_bf16* __restr
                 float o[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = rstd * (q[c][e] - mq - v[c][e] * mqx);
+                if (dres != nullptr) {                               // gradient of the residual branch around the LayerNorm (x + f(LN(x)))
+                    const u32x4_t rw = *(const u32x4_t*)(dres + row * lddres + ch * 8);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { o[2 * e] += bf16lo_to_f32(rw[e]); o[2 * e + 1] += bf16hi_to_f32(rw[e]); }
+                }
                 const u32x4_t w = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
                 *(u32x4_t*)(dx + row * lddx + ch * 8) = w;
             }
@@ -249,23 +262,25 @@ __device__ __forceinline__ float gelu_tanh_grad(float a) {
 }
 
 template <bool TANH>
-__global__ __launch_bounds__(256) void gelu_bwd(const ov_bf16* __restrict__ a, int64_t lda, const ov_bf16* __restrict__ dh, int64_t lddh,
-                                                ov_bf16* __restrict__ da, int64_t ldda, int64_t rows, int nchunk) {
+__global__ __launch_bounds__(256) void gelu_bwd(const ov_bf16* a, int64_t lda, const ov_bf16* dh, int64_t lddh, ov_bf16* da, int64_t ldda,
+                                                ov_bf16* h_out, int64_t ldh, int64_t rows, int nchunk) {   // da may alias dh, h_out may alias a
     const int64_t total = rows * nchunk;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t r = i / nchunk;
         const int c = (int)(i - r * nchunk) * 8;
         const u32x4_t av = *(const u32x4_t*)(a + r * lda + c);
         const u32x4_t dv = *(const u32x4_t*)(dh + r * lddh + c);
-        u32x4_t o;
+        u32x4_t o, ho;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float a0 = bf16lo_to_f32(av[e]), a1 = bf16hi_to_f32(av[e]);
             const float g0 = TANH ? gelu_tanh_grad(a0) : gelu_erf_grad(a0);
             const float g1 = TANH ? gelu_tanh_grad(a1) : gelu_erf_grad(a1);
             o[e] = pack_bf16x2(bf16lo_to_f32(dv[e]) * g0, bf16hi_to_f32(dv[e]) * g1);
+            ho[e] = TANH ? pack_bf16x2(gelu_tanh_f(a0), gelu_tanh_f(a1)) : pack_bf16x2(gelu_erf_f(a0), gelu_erf_f(a1));
         }
         *(u32x4_t*)(da + r * ldda + c) = o;
+        if (h_out != nullptr) *(u32x4_t*)(h_out + r * ldh + c) = ho;
     }
 }
 
@@ -319,9 +334,9 @@ extern "C" size_t ov_linear_backward_workspace_bytes(int64_t M, int N, int K) {
 extern "C" int ov_linear_backward(const ov_bf16* dY, int64_t lddy, const ov_bf16* X, int64_t ldx, const ov_bf16* W, int64_t ldw,
                                   int64_t M, int N, int K, ov_bf16* dX, int64_t lddx, ov_bf16* dW, int64_t lddw, float* db,
                                   void* workspace, size_t workspace_bytes, ov_stream_t stream) {
-    if (!dY || !X || !W || !workspace || M <= 0 || N <= 0 || K <= 0) return OV_ERR_INVALID;
-    if (!dX && !dW && !db) return OV_ERR_INVALID;
-    if (N % 64 || K % 64 || lddy % 8 || ldx % 8 || ldw % 8 || lddy < N || ldx < K || ldw < K) return OV_ERR_UNSUPPORTED;
+    if (!dY || !W || !workspace || M <= 0 || N <= 0 || K <= 0) return OV_ERR_INVALID;
+    if ((!dX && !dW && !db) || (dW && !X)) return OV_ERR_INVALID;
+    if (N % 64 || K % 64 || lddy % 8 || ldw % 8 || lddy < N || ldw < K || (X && (ldx % 8 || ldx < K))) return OV_ERR_UNSUPPORTED;
     if ((dX && (lddx % 8 || lddx < K)) || (dW && (lddw % 8 || lddw < K))) return OV_ERR_UNSUPPORTED;
     if (((uintptr_t)dY | (uintptr_t)X | (uintptr_t)W | (uintptr_t)dX | (uintptr_t)dW | (uintptr_t)db | (uintptr_t)workspace) & 15)
         return OV_ERR_INVALID;
@@ -379,23 +394,24 @@ extern "C" size_t ov_layernorm_backward_workspace_bytes(int64_t rows, int D) {
     return (size_t)lnb_blocks(rows) * 4 * 2 * D * sizeof(float) + (size_t)RS_SPLIT * D * sizeof(float);
 }
 
-extern "C" int ov_layernorm_backward(const ov_bf16* x, int64_t ldx, const float* gamma, const ov_bf16* dy, int64_t lddy, ov_bf16* dx,
-                                     int64_t lddx, float* dgamma, float* dbeta, int64_t rows, int D, float eps, void* workspace,
-                                     size_t workspace_bytes, ov_stream_t stream) {
+extern "C" int ov_layernorm_backward(const ov_bf16* x, int64_t ldx, const float* gamma, const ov_bf16* dy, int64_t lddy,
+                                     const ov_bf16* dres, int64_t lddres, ov_bf16* dx, int64_t lddx, float* dgamma, float* dbeta,
+                                     int64_t rows, int D, float eps, void* workspace, size_t workspace_bytes, ov_stream_t stream) {
     if (!x || !gamma || !dy || !dx || !dgamma || !dbeta || !workspace || rows <= 0 || D <= 0) return OV_ERR_INVALID;
     if (D % 8 || D > 4096 || ldx % 8 || lddy % 8 || lddx % 8 || ldx < D || lddy < D || lddx < D) return OV_ERR_UNSUPPORTED;
-    if (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)workspace) & 15) return OV_ERR_INVALID;
+    if (dres && (lddres % 8 || lddres < D)) return OV_ERR_UNSUPPORTED;
+    if (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)dy | (uintptr_t)dres | (uintptr_t)dx | (uintptr_t)workspace) & 15) return OV_ERR_INVALID;
     if (workspace_bytes < ov_layernorm_backward_workspace_bytes(rows, D)) return OV_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const int64_t blocks = lnb_blocks(rows);
     const dim3 grid((unsigned)blocks), blk(256);
     float* part = (float*)workspace;
     const int nch = (D / 8 + 63) / 64;
-    if (nch <= 1) hipLaunchKernelGGL(layernorm_bwd_rows<1>, grid, blk, 0, st, x, ldx, gamma, dy, lddy, dx, lddx, rows, D, eps, part);
-    else if (nch <= 2) hipLaunchKernelGGL(layernorm_bwd_rows<2>, grid, blk, 0, st, x, ldx, gamma, dy, lddy, dx, lddx, rows, D, eps, part);
-    else if (nch <= 3) hipLaunchKernelGGL(layernorm_bwd_rows<3>, grid, blk, 0, st, x, ldx, gamma, dy, lddy, dx, lddx, rows, D, eps, part);
-    else if (nch <= 4) hipLaunchKernelGGL(layernorm_bwd_rows<4>, grid, blk, 0, st, x, ldx, gamma, dy, lddy, dx, lddx, rows, D, eps, part);
-    else hipLaunchKernelGGL(layernorm_bwd_rows<8>, grid, blk, 0, st, x, ldx, gamma, dy, lddy, dx, lddx, rows, D, eps, part);
+    if (nch <= 1) hipLaunchKernelGGL(layernorm_bwd_rows<1>, grid, blk, 0, st, x, ldx, gamma, dy, lddy, dres, lddres, dx, lddx, rows, D, eps, part);
+    else if (nch <= 2) hipLaunchKernelGGL(layernorm_bwd_rows<2>, grid, blk, 0, st, x, ldx, gamma, dy, lddy, dres, lddres, dx, lddx, rows, D, eps, part);
+    else if (nch <= 3) hipLaunchKernelGGL(layernorm_bwd_rows<3>, grid, blk, 0, st, x, ldx, gamma, dy, lddy, dres, lddres, dx, lddx, rows, D, eps, part);
+    else if (nch <= 4) hipLaunchKernelGGL(layernorm_bwd_rows<4>, grid, blk, 0, st, x, ldx, gamma, dy, lddy, dres, lddres, dx, lddx, rows, D, eps, part);
+    else hipLaunchKernelGGL(layernorm_bwd_rows<8>, grid, blk, 0, st, x, ldx, gamma, dy, lddy, dres, lddres, dx, lddx, rows, D, eps, part);
     OV_LAUNCH_CHECK();
     // part[w][0][:] = dgamma partial, part[w][1][:] = dbeta partial of wave w: two strided column sums
     float* scratch = part + (size_t)blocks * 4 * 2 * D;
@@ -404,17 +420,93 @@ extern "C" int ov_layernorm_backward(const ov_bf16* x, int64_t ldx, const float*
     return launch_rows_sum(part + D, blocks * 4, D, (int64_t)2 * D, scratch, dbeta, st);
 }
 
-extern "C" int ov_gelu_backward(const ov_bf16* a, int64_t lda, const ov_bf16* dh, int64_t lddh, ov_bf16* da, int64_t ldda, int64_t rows,
-                                int N, int tanh_form, ov_stream_t stream) {
+extern "C" int ov_gelu_backward(const ov_bf16* a, int64_t lda, const ov_bf16* dh, int64_t lddh, ov_bf16* da, int64_t ldda, ov_bf16* h_out,
+                                int64_t ldh, int64_t rows, int N, int tanh_form, ov_stream_t stream) {
     if (!a || !dh || !da || rows <= 0 || N <= 0) return OV_ERR_INVALID;
     if (N % 8 || lda % 8 || lddh % 8 || ldda % 8 || lda < N || lddh < N || ldda < N) return OV_ERR_UNSUPPORTED;
-    if (((uintptr_t)a | (uintptr_t)dh | (uintptr_t)da) & 15) return OV_ERR_INVALID;
+    if (h_out && (ldh % 8 || ldh < N)) return OV_ERR_UNSUPPORTED;
+    if (((uintptr_t)a | (uintptr_t)dh | (uintptr_t)da | (uintptr_t)h_out) & 15) return OV_ERR_INVALID;
     const int64_t total = rows * (N / 8);
     int64_t blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     hipStream_t st = (hipStream_t)stream;
-    if (tanh_form) hipLaunchKernelGGL(gelu_bwd<true>, dim3((unsigned)blocks), dim3(256), 0, st, a, lda, dh, lddh, da, ldda, rows, N / 8);
-    else hipLaunchKernelGGL(gelu_bwd<false>, dim3((unsigned)blocks), dim3(256), 0, st, a, lda, dh, lddh, da, ldda, rows, N / 8);
+    if (tanh_form) hipLaunchKernelGGL(gelu_bwd<true>, dim3((unsigned)blocks), dim3(256), 0, st, a, lda, dh, lddh, da, ldda, h_out, ldh, rows, N / 8);
+    else hipLaunchKernelGGL(gelu_bwd<false>, dim3((unsigned)blocks), dim3(256), 0, st, a, lda, dh, lddh, da, ldda, h_out, ldh, rows, N / 8);
     OV_LAUNCH_CHECK();
+    return OV_OK;
+}
+
+// ---- one ResidualAttentionBlock (transformer.py:254-265: x1 = x + attn(ln_1(x)); y = x1 + mlp(ln_2(x1))) ----------------------
+// Activation recomputation: only the block input x is kept by the caller; ln_1, qkv, attention, x1, ln_2 and the c_fc
+// pre-activation are recomputed here with the forward's own kernels, then the chain rule runs back through the operators above.
+namespace {
+struct BlockBufs { ov_bf16 *n1, *qkv, *o, *x1, *n2, *a, *dh, *t1, *dx1, *dqkv; char* lin; char* ln; size_t lin_bytes, ln_bytes, total; };
+inline BlockBufs plan_block(const ov_tower_cfg* c, int64_t M, char* base) {
+    const int D = c->width, F = c->mlp_pad;
+    BlockBufs b;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align256(bytes); return p; };
+    b.n1 = (ov_bf16*)take((size_t)M * D * 2);   b.qkv = (ov_bf16*)take((size_t)M * 3 * D * 2);  b.o = (ov_bf16*)take((size_t)M * D * 2);
+    b.x1 = (ov_bf16*)take((size_t)M * D * 2);   b.n2 = (ov_bf16*)take((size_t)M * D * 2);       b.a = (ov_bf16*)take((size_t)M * F * 2);
+    b.dh = (ov_bf16*)take((size_t)M * F * 2);   b.t1 = (ov_bf16*)take((size_t)M * D * 2);       b.dx1 = (ov_bf16*)take((size_t)M * D * 2);
+    b.dqkv = (ov_bf16*)take((size_t)M * 3 * D * 2);
+    size_t lb = ov_linear_backward_workspace_bytes(M, 3 * D, D);
+    const size_t l2 = ov_linear_backward_workspace_bytes(M, D, D), l3 = ov_linear_backward_workspace_bytes(M, F, D),
+                 l4 = ov_linear_backward_workspace_bytes(M, D, F);
+    lb = lb > l2 ? lb : l2; lb = lb > l3 ? lb : l3; lb = lb > l4 ? lb : l4;
+    b.lin_bytes = lb; b.lin = take(lb);
+    b.ln_bytes = ov_layernorm_backward_workspace_bytes(M, D); b.ln = take(b.ln_bytes);
+    b.total = off;
+    return b;
+}
+inline bool block_cfg_ok(const ov_tower_cfg* c) {
+    return c && c->width > 0 && c->heads > 0 && c->width % 64 == 0 && c->width == c->heads * 64 && c->mlp == c->mlp_pad && c->mlp % 64 == 0 &&
+           c->width <= 4096;
+}
+}  // namespace
+
+extern "C" size_t ov_block_backward_workspace_bytes(const ov_tower_cfg* cfg, int B, int L) {
+    if (!block_cfg_ok(cfg) || B <= 0 || L <= 0) return 0;
+    return plan_block(cfg, (int64_t)B * L, nullptr).total;
+}
+
+extern "C" int ov_block_backward(const ov_tower_cfg* cfg, const ov_block_weights* w, const ov_bf16* x, const ov_bf16* dy, ov_bf16* dx,
+                                 const ov_block_grads* g, int B, int L, void* workspace, size_t workspace_bytes, ov_stream_t stream) {
+    if (!cfg || !w || !x || !dy || !dx || !g || !workspace || B <= 0 || L <= 0) return OV_ERR_INVALID;
+    if (!block_cfg_ok(cfg) || L > 288) return OV_ERR_UNSUPPORTED;             // head_dim 64, unpadded MLP, attention backward's L limit
+    if (w->qkv_colsum || w->fc_colsum) return OV_ERR_UNSUPPORTED;             // needs the module's own (unfolded) weights
+    if (!w->ln1_w || !w->ln1_b || !w->qkv_w || !w->qkv_b || !w->out_w || !w->out_b || !w->ln2_w || !w->ln2_b || !w->fc_w || !w->fc_b ||
+        !w->proj_w || !w->proj_b)
+        return OV_ERR_INVALID;
+    if (!g->ln1_w || !g->ln1_b || !g->qkv_w || !g->qkv_b || !g->out_w || !g->out_b || !g->ln2_w || !g->ln2_b || !g->fc_w || !g->fc_b ||
+        !g->proj_w || !g->proj_b)
+        return OV_ERR_INVALID;
+    const int D = cfg->width, F = cfg->mlp_pad, H = cfg->heads;
+    const int64_t M = (int64_t)B * L;
+    if (workspace_bytes < ov_block_backward_workspace_bytes(cfg, B, L)) return OV_ERR_WORKSPACE;
+    if (((uintptr_t)workspace | (uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) return OV_ERR_INVALID;
+    const BlockBufs b = plan_block(cfg, M, (char*)workspace);
+    const float eps = cfg->ln_eps, scale = 0.125f;
+    int rc;
+#define OV_TRY(call) do { if ((rc = (call)) != OV_OK) return rc; } while (0)
+    // ---- recompute the forward's intermediates
+    OV_TRY(ov_layernorm(x, OV_BF16, D, w->ln1_w, w->ln1_b, b.n1, OV_BF16, D, M, D, eps, stream));
+    OV_TRY(ov_gemm(b.n1, D, w->qkv_w, D, w->qkv_b, b.qkv, 3 * D, M, 3 * D, D, OV_EPI_BIAS, nullptr, 0, 0, 0, 0, stream));
+    OV_TRY(ov_attention(b.qkv, 3 * D, b.o, D, B, L, H, 64, scale, stream));
+    OV_TRY(ov_gemm(b.o, D, w->out_w, D, w->out_b, b.x1, D, M, D, D, OV_EPI_BIAS_RESIDUAL, x, D, 0, 0, 0, stream));
+    OV_TRY(ov_layernorm(b.x1, OV_BF16, D, w->ln2_w, w->ln2_b, b.n2, OV_BF16, D, M, D, eps, stream));
+    OV_TRY(ov_gemm(b.n2, D, w->fc_w, D, w->fc_b, b.a, F, M, F, D, OV_EPI_BIAS, nullptr, 0, 0, 0, 0, stream));
+    // ---- MLP branch: y = x1 + c_proj(gelu(a))
+    OV_TRY(ov_linear_backward(dy, D, nullptr, 0, w->proj_w, F, M, D, F, b.dh, F, nullptr, 0, nullptr, b.lin, b.lin_bytes, stream));      // dh = dy Wproj
+    OV_TRY(ov_gelu_backward(b.a, F, b.dh, F, b.dh, F, b.a, F, M, F, cfg->gelu_tanh, stream));                                          // dh -> da, a -> gelu(a), in place
+    OV_TRY(ov_linear_backward(dy, D, b.a, F, w->proj_w, F, M, D, F, nullptr, 0, g->proj_w, F, g->proj_b, b.lin, b.lin_bytes, stream));
+    OV_TRY(ov_linear_backward(b.dh, F, b.n2, D, w->fc_w, D, M, F, D, b.t1, D, g->fc_w, D, g->fc_b, b.lin, b.lin_bytes, stream));        // t1 = d ln_2 out
+    OV_TRY(ov_layernorm_backward(b.x1, D, w->ln2_w, b.t1, D, dy, D, b.dx1, D, g->ln2_w, g->ln2_b, M, D, eps, b.ln, b.ln_bytes, stream)); // dx1 = dy + ...
+    // ---- attention branch: x1 = x + out_proj(attn(qkv))
+    OV_TRY(ov_linear_backward(b.dx1, D, b.o, D, w->out_w, D, M, D, D, b.t1, D, g->out_w, D, g->out_b, b.lin, b.lin_bytes, stream));     // t1 = d attention out
+    OV_TRY(ov_attention_backward(b.qkv, 3 * D, b.o, D, b.t1, D, b.dqkv, 3 * D, B, L, H, 64, scale, stream));
+    OV_TRY(ov_linear_backward(b.dqkv, 3 * D, b.n1, D, w->qkv_w, D, M, 3 * D, D, b.t1, D, g->qkv_w, D, g->qkv_b, b.lin, b.lin_bytes, stream));  // t1 = d ln_1 out
+    OV_TRY(ov_layernorm_backward(x, D, w->ln1_w, b.t1, D, b.dx1, D, dx, D, g->ln1_w, g->ln1_b, M, D, eps, b.ln, b.ln_bytes, stream));
+#undef OV_TRY
     return OV_OK;
 }

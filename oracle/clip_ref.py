@@ -120,6 +120,40 @@ def resblock(x: torch.Tensor, sd: Dict[str, torch.Tensor], p: str, heads: int, t
     return x + h
 
 
+def resblock_backward(x, dy, sd, p: str, heads: int, tanh_gelu: bool, eps: float = LN_EPS):
+    """Backward of ``resblock`` (what autograd computes through transformer.py:254-265), composed from the closed-form operator
+    backwards above, fp32.  Returns (dx, {reference parameter name (without prefix): gradient})."""
+    f = lambda k: sd[p + k].float()
+    x, dy = x.float(), dy.float()
+    B, L, D = x.shape
+    hd = D // heads
+    split = lambda t: t.reshape(B, L, heads, hd).transpose(1, 2)
+    merge = lambda t: t.transpose(1, 2).reshape(B, L, D)
+    # forward intermediates
+    n1 = layer_norm(x, f("ln_1.weight"), f("ln_1.bias"), eps)
+    qkv = F.linear(n1, f("attn.in_proj_weight"), f("attn.in_proj_bias"))
+    q, k, v = [split(t) for t in qkv.split(D, dim=-1)]
+    o = merge(torch.softmax((q * hd ** -0.5) @ k.transpose(-1, -2), dim=-1) @ v)
+    x1 = x + F.linear(o, f("attn.out_proj.weight"), f("attn.out_proj.bias"))
+    n2 = layer_norm(x1, f("ln_2.weight"), f("ln_2.bias"), eps)
+    a = F.linear(n2, f("mlp.c_fc.weight"), f("mlp.c_fc.bias"))
+    h = gelu(a, tanh_gelu)
+    g = {}
+    # MLP branch
+    dh, g["mlp.c_proj.weight"], g["mlp.c_proj.bias"] = linear_backward(dy, h, f("mlp.c_proj.weight"))
+    da = gelu_backward(a, dh, tanh_gelu)
+    dn2, g["mlp.c_fc.weight"], g["mlp.c_fc.bias"] = linear_backward(da, n2, f("mlp.c_fc.weight"))
+    dl, g["ln_2.weight"], g["ln_2.bias"] = layer_norm_backward(x1, f("ln_2.weight"), dn2, eps)
+    dx1 = dy + dl
+    # attention branch
+    do, g["attn.out_proj.weight"], g["attn.out_proj.bias"] = linear_backward(dx1, o, f("attn.out_proj.weight"))
+    dq, dk, dv = attention_backward(q, k, v, split(do), hd ** -0.5)
+    dqkv = torch.cat([merge(dq), merge(dk), merge(dv)], dim=-1)
+    dn1, g["attn.in_proj_weight"], g["attn.in_proj_bias"] = linear_backward(dqkv, n1, f("attn.in_proj_weight"))
+    dl, g["ln_1.weight"], g["ln_1.bias"] = layer_norm_backward(x, f("ln_1.weight"), dn1, eps)
+    return dx1 + dl, g
+
+
 def block_stack(x, sd, prefix: str, layers: int, heads: int, tanh_gelu: bool, eps: float = LN_EPS):
     """Transformer.forward, transformer.py:355-366."""
     for i in range(layers):

@@ -20,6 +20,7 @@ Files written (np.savez_compressed):
   small8_384.npz          S/8@384, B=1 (2305 tokens): features, token slices
   cliploss_ws.npz         ClipLoss(local_loss=True) per-rank losses at world_size 2 and 8 over gloo
   opgrad.npz              autograd through the reference's LayerNorm / nn.Linear / nn.GELU for random upstream gradients
+  blockgrad.npz           autograd through the reference ResidualAttentionBlock (Tiny block 0): d input + parameter gradients
   cliploss_grad.npz       autograd gradients of ClipLoss at world_size 1 and per rank at world_size 2
 """
 from __future__ import annotations
@@ -372,6 +373,29 @@ def gen_opgrad(tr, out):
     np.savez_compressed(out, **res)
 
 
+def gen_blockgrad(tr, out):
+    """autograd through the reference ResidualAttentionBlock (transformer.py:210-265) of the Tiny vision tower, formula weights
+    of block 0, a random upstream gradient: d input and every parameter gradient (weight matrices: first 6 rows + Frobenius norm)."""
+    g = torch.Generator().manual_seed(777)
+    cfg = ovcfg.preset("vit-tiny-patch16-160")
+    sd = synth.make_state_dict(cfg, 0)
+    blk = tr.ResidualAttentionBlock(192, 3, 4.0, batch_first=True, norm_layer=lambda d: tr.LayerNorm(d, eps=1e-6))
+    p = "visual.transformer.resblocks.0."
+    blk.load_state_dict({k[len(p):]: v for k, v in sd.items() if k.startswith(p)}, strict=True)
+    x = torch.randn(2, 101, 192, generator=g).requires_grad_(True)
+    dy = torch.randn(2, 101, 192, generator=g)
+    blk(x).backward(dy)
+    res = {"x": f32(x), "dy": f32(dy), "dx": f32(x.grad)}
+    for name, prm in blk.named_parameters():
+        gr = prm.grad
+        if gr.dim() == 2:
+            res["g." + name + ".head"] = f32(gr[:6])
+            res["g." + name + ".norm"] = np.float64(gr.double().norm())
+        else:
+            res["g." + name] = f32(gr)
+    np.savez_compressed(out, **res)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -389,6 +413,7 @@ def main():
         "cliploss": lambda: gen_cliploss(lossmod, a.ref, os.path.join(HERE, "cliploss_ws.npz")),
         "preprocess": lambda: gen_preprocess(a.ref, os.path.join(HERE, "preprocess.npz")),
         "opgrad": lambda: gen_opgrad(tr, os.path.join(HERE, "opgrad.npz")),
+        "blockgrad": lambda: gen_blockgrad(tr, os.path.join(HERE, "blockgrad.npz")),
         "lossgrad": lambda: gen_lossgrad(lossmod, a.ref, os.path.join(HERE, "cliploss_grad.npz")),
     }
     for k, fn in jobs.items():

@@ -168,7 +168,7 @@ def transpose(x):
     return out
 
 
-def layernorm_backward(x, gamma, dy, eps=1e-6):
+def layernorm_backward(x, gamma, dy, eps=1e-6, dres=None):
     lib = _lib.load()
     rows, D = x.shape
     dx = torch.empty_like(x)
@@ -176,18 +176,38 @@ def layernorm_backward(x, gamma, dy, eps=1e-6):
     db = torch.empty(D, dtype=torch.float32, device=x.device)
     nb = lib.ov_layernorm_backward_workspace_bytes(rows, D)
     ws = torch.empty(nb + 256, dtype=torch.uint8, device=x.device)
-    check(lib.ov_layernorm_backward(ptr(x), x.stride(0), ptr(gamma), ptr(dy), dy.stride(0), ptr(dx), dx.stride(0), ptr(dg), ptr(db),
+    check(lib.ov_layernorm_backward(ptr(x), x.stride(0), ptr(gamma), ptr(dy), dy.stride(0), ptr(dres) if dres is not None else None,
+                                    dres.stride(0) if dres is not None else 0, ptr(dx), dx.stride(0), ptr(dg), ptr(db),
                                     rows, D, eps, ptr(ws), nb, stream_ptr()), "ov_layernorm_backward")
     return dx, dg, db
 
 
-def gelu_backward(a, dh, tanh):
+def gelu_backward(a, dh, tanh, with_h=False):
     lib = _lib.load()
     rows, N = a.shape
     da = torch.empty_like(a)
-    check(lib.ov_gelu_backward(ptr(a), a.stride(0), ptr(dh), dh.stride(0), ptr(da), da.stride(0), rows, N, int(tanh), stream_ptr()),
-          "ov_gelu_backward")
-    return da
+    h = torch.empty_like(a) if with_h else None
+    check(lib.ov_gelu_backward(ptr(a), a.stride(0), ptr(dh), dh.stride(0), ptr(da), da.stride(0), ptr(h) if with_h else None,
+                               h.stride(0) if with_h else 0, rows, N, int(tanh), stream_ptr()), "ov_gelu_backward")
+    return (da, h) if with_h else da
+
+
+def block_backward(cfg, weights, x, dy, B, L):
+    """ov_block_backward.  weights: dict of the module's own tensors (ln1_w, ln1_b fp32; qkv_w bf16 [3D, D]; qkv_b fp32; ...).
+    Returns (dx bf16, grads dict)."""
+    import ctypes as C
+    lib = _lib.load()
+    names = ("ln1_w", "ln1_b", "qkv_w", "qkv_b", "out_w", "out_b", "ln2_w", "ln2_b", "fc_w", "fc_b", "proj_w", "proj_b")
+    wst = _lib.BlockWeights(*[C.c_void_p(weights[n].data_ptr()) for n in names], None, None)
+    grads = {n: torch.empty_like(weights[n]) for n in names}
+    gst = _lib.BlockGrads(*[C.c_void_p(grads[n].data_ptr()) for n in names])
+    dx = torch.empty_like(x)
+    nb = lib.ov_block_backward_workspace_bytes(C.byref(cfg), B, L)
+    assert nb > 0
+    ws = torch.empty(nb + 256, dtype=torch.uint8, device=x.device)
+    check(lib.ov_block_backward(C.byref(cfg), C.byref(wst), ptr(x), ptr(dy), ptr(dx), C.byref(gst), B, L, ptr(ws), nb, stream_ptr()),
+          "ov_block_backward")
+    return dx, grads
 
 
 def attention_backward(qkv, out, dout, B, L, H, hd=64):

@@ -352,6 +352,77 @@ def test_attention_backward_golden_reference():
     assert float((dx - g["mha_dx"]).abs().max()) < 3e-2 * float(g["mha_dx"].abs().max()) + 2e-3
 
 
+def _block_case(D, heads, mlp, B, L, tanh, seed):
+    """Random block: returns (reference-named fp32 state dict of bf16-rounded weights, C-ABI weight dict on the device, x, dy)."""
+    names = {"ln1_w": ("ln_1.weight", (D,), 1.0, 0.1), "ln1_b": ("ln_1.bias", (D,), 0.0, 0.1),
+             "qkv_w": ("attn.in_proj_weight", (3 * D, D), 0.0, D ** -0.5), "qkv_b": ("attn.in_proj_bias", (3 * D,), 0.0, 0.05),
+             "out_w": ("attn.out_proj.weight", (D, D), 0.0, D ** -0.5), "out_b": ("attn.out_proj.bias", (D,), 0.0, 0.05),
+             "ln2_w": ("ln_2.weight", (D,), 1.0, 0.1), "ln2_b": ("ln_2.bias", (D,), 0.0, 0.1),
+             "fc_w": ("mlp.c_fc.weight", (mlp, D), 0.0, D ** -0.5), "fc_b": ("mlp.c_fc.bias", (mlp,), 0.0, 0.05),
+             "proj_w": ("mlp.c_proj.weight", (D, mlp), 0.0, mlp ** -0.5), "proj_b": ("mlp.c_proj.bias", (D,), 0.0, 0.05)}
+    sd, dev = {}, {}
+    for i, (k, (ref, shape, mean, std)) in enumerate(names.items()):
+        t = rnd(*shape, seed=seed + i) * std + mean
+        if len(shape) == 2:
+            t = bf(t)
+            dev[k] = t.to(DEV)
+        else:
+            dev[k] = t.to(DEV)
+        sd["b." + ref] = t.float()
+    x, dy = bf(rnd(B, L, D, seed=seed + 20)), bf(rnd(B, L, D, seed=seed + 21))
+    return names, sd, dev, x, dy
+
+
+@pytest.mark.parametrize("D,heads,mlp,B,L,tanh", [(192, 3, 768, 2, 101, False), (1024, 16, 4096, 2, 257, False), (768, 12, 3072, 3, 80, True)])
+def test_block_backward_vs_oracle(D, heads, mlp, B, L, tanh):
+    """ov_block_backward (recompute + chain rule through the HIP operators) vs the oracle's closed-form block backward in fp32 on the
+    same bf16 weights and inputs.  Every intermediate of the HIP path is bf16, so the comparison is relative to each gradient's
+    scale: 4e-2 of its maximum (weights: Frobenius-relative 2e-2)."""
+    from openvision_amd import _lib as L_
+    names, sd, dev, x, dy = _block_case(D, heads, mlp, B, L, tanh, 60)
+    cfg = L_.TowerCfg(D, 1, heads, mlp, mlp, int(tanh), 1e-6)
+    dx, grads = H_.block_backward(cfg, dev, x.reshape(B * L, D).to(DEV), dy.reshape(B * L, D).to(DEV), B, L)
+    rdx, rg = R.resblock_backward(x, dy, sd, "b.", heads, tanh, 1e-6)
+    err = float((dx.float().cpu().view(B, L, D) - rdx).abs().max())
+    assert err < 4e-2 * float(rdx.abs().max()), ("dx", err, float(rdx.abs().max()))
+    for k, (ref, shape, _, _) in names.items():
+        got, want = grads[k].float().cpu(), rg[ref]
+        if len(shape) == 2:
+            rel = float((got - want).norm() / want.norm())
+            assert rel < 2e-2, (k, rel)
+        else:
+            e = float((got - want).abs().max())
+            assert e < 4e-2 * float(want.abs().max()) + 1e-3, (k, e, float(want.abs().max()))
+
+
+def test_block_backward_golden_reference():
+    """The Tiny block 0 of the formula weights against autograd through the reference ResidualAttentionBlock (blockgrad.npz)."""
+    from conftest import golden
+    from openvision_amd import _lib as L_, config as ovcfg, synth
+    g = golden("blockgrad.npz")
+    sd = synth.make_state_dict(ovcfg.preset("vit-tiny-patch16-160"), 0)
+    p = "visual.transformer.resblocks.0."
+    ref_names = {"ln1_w": "ln_1.weight", "ln1_b": "ln_1.bias", "qkv_w": "attn.in_proj_weight", "qkv_b": "attn.in_proj_bias",
+                 "out_w": "attn.out_proj.weight", "out_b": "attn.out_proj.bias", "ln2_w": "ln_2.weight", "ln2_b": "ln_2.bias",
+                 "fc_w": "mlp.c_fc.weight", "fc_b": "mlp.c_fc.bias", "proj_w": "mlp.c_proj.weight", "proj_b": "mlp.c_proj.bias"}
+    dev = {k: (bf(sd[p + r]) if sd[p + r].dim() == 2 else sd[p + r].float()).contiguous().to(DEV) for k, r in ref_names.items()}
+    x, dy = torch.from_numpy(g["x"]), torch.from_numpy(g["dy"])
+    cfg = L_.TowerCfg(192, 1, 3, 768, 768, 0, 1e-6)
+    dx, grads = H_.block_backward(cfg, dev, bf(x).reshape(202, 192).to(DEV), bf(dy).reshape(202, 192).to(DEV), 2, 101)
+    want = torch.from_numpy(g["dx"])
+    assert float((dx.float().cpu().view(2, 101, 192) - want).abs().max()) < 5e-2 * float(want.abs().max())
+    for k, r in ref_names.items():
+        got = grads[k].float().cpu()
+        if got.dim() == 2:
+            norm = float(g["g." + r + ".norm"])
+            assert abs(float(got.double().norm()) - norm) < 3e-2 * norm, k
+            head = torch.from_numpy(g["g." + r + ".head"])
+            assert float((got[:6] - head).abs().max()) < 6e-2 * float(head.abs().max()) + 1e-3, k
+        else:
+            w = torch.from_numpy(g["g." + r])
+            assert float((got - w).abs().max()) < 5e-2 * float(w.abs().max()) + 1e-3, k
+
+
 def test_operator_backward_golden_reference():
     """LayerNorm and Linear backward through the C ABI vs autograd through the reference's modules (opgrad.npz), on the
     golden's inputs rounded to bf16 (the kernels' I/O type): tolerance = bf16 input and output rounding."""

@@ -159,3 +159,24 @@ def test_oracle_attention_backward_matches_reference_autograd():
     dqkv = torch.cat([t.transpose(1, 2).reshape(B, L, D) for t in (dq, dk, dv)], dim=-1)
     assert (dqkv @ w - g["mha_dx"]).abs().max() < 2e-5
     assert (dqkv.reshape(-1, 3 * D).T @ x.reshape(-1, D) - g["mha_dw"]).abs().max() < 5e-5
+
+
+def _check_block_grads(g, grads, dx, rtol_w, atol):
+    assert (dx - torch.from_numpy(g["dx"])).abs().max() < atol
+    for name, gr in grads.items():
+        if gr.dim() == 2:
+            head, norm = torch.from_numpy(g["g." + name + ".head"]), float(g["g." + name + ".norm"])
+            assert (gr[:6].float() - head).abs().max() < atol + rtol_w * float(head.abs().max()), name
+            assert abs(float(gr.double().norm()) - norm) < rtol_w * norm + atol, name
+        else:
+            want = torch.from_numpy(g["g." + name])
+            assert (gr.float() - want).abs().max() < atol + rtol_w * float(want.abs().max()), name
+
+
+def test_oracle_block_backward_matches_reference_autograd():
+    """oracle.resblock_backward (closed-form composition) vs autograd through the reference ResidualAttentionBlock (blockgrad.npz)."""
+    g = golden("blockgrad.npz")
+    cfg = ovcfg.preset("vit-tiny-patch16-160")
+    sd = synth.make_state_dict(cfg, 0)
+    dx, grads = R.resblock_backward(torch.from_numpy(g["x"]), torch.from_numpy(g["dy"]), sd, "visual.transformer.resblocks.0.", 3, False, 1e-6)
+    _check_block_grads(g, grads, dx, 1e-4, 5e-5)
