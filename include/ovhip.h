@@ -348,6 +348,16 @@ size_t ov_block_backward_workspace_bytes(const ov_tower_cfg* cfg, int B, int L);
 int ov_block_backward(const ov_tower_cfg* cfg, const ov_block_weights* w, const ov_bf16* x, const ov_bf16* dy, ov_bf16* dx,
                       const ov_block_grads* g, int B, int L, void* workspace, size_t workspace_bytes, ov_stream_t stream);
 
+/* Training-side tower entry points.  ov_tower_forward_saving = ov_tower_forward on the caller's stream that also copies every
+ * block's INPUT into saved_inputs [layers][B*L, D] (bf16 path only; the blocks must hold the module's own, unfolded weights for the
+ * backward).  ov_tower_backward runs ov_block_backward over the layers in reverse: dx [B*L, D] holds d loss / d (tower output) on
+ * entry and d loss / d (tower input) on return; grads[layer] receives that block's parameter gradients (written, not accumulated). */
+int    ov_tower_forward_saving(const ov_tower* t, ov_bf16* x, ov_bf16* saved_inputs, int B, int L, void* workspace,
+                               size_t workspace_bytes, ov_stream_t stream);
+size_t ov_tower_backward_workspace_bytes(const ov_tower* t, int B, int L);
+int    ov_tower_backward(const ov_tower* t, const ov_bf16* saved_inputs, ov_bf16* dx, const ov_block_grads* grads, int B, int L,
+                         void* workspace, size_t workspace_bytes, ov_stream_t stream);
+
 typedef struct {      /* VisionTransformer front/back ends (OpenVision: no ln_pre, no conv bias) */
     int image_size, patch_size, kpad;              /* kpad = roundup(3*P*P, 64) */
     int pool_avg;                                  /* 1 = 'avg' (skip cls), 0 = 'tok' */

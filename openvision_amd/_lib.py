@@ -103,6 +103,9 @@ SIGNATURES = {
                                       c_void_p, c_int64, c_int, c_float, c_void_p, c_size_t, c_void_p]),
     "ov_gelu_backward": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int,
                                  c_void_p]),
+    "ov_tower_forward_saving": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "ov_tower_backward_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
+    "ov_tower_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "ov_block_backward_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
     "ov_block_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "ov_clip_loss_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p,

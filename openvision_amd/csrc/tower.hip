@@ -426,6 +426,55 @@ extern "C" int ov_tower_forward(const ov_tower* t, ov_bf16* x, int B, int L, voi
     return OV_OK;
 }
 
+// ---- training-side entry points: keep every block's input, run the blocks' backward in reverse -------------
+extern "C" int ov_block_backward(const ov_tower_cfg* cfg, const ov_block_weights* w, const ov_bf16* x, const ov_bf16* dy, ov_bf16* dx,
+                                 const ov_block_grads* g, int B, int L, void* workspace, size_t workspace_bytes, ov_stream_t stream);
+extern "C" size_t ov_block_backward_workspace_bytes(const ov_tower_cfg* cfg, int B, int L);
+
+extern "C" int ov_tower_forward_saving(const ov_tower* t, ov_bf16* x, ov_bf16* saved_inputs, int B, int L, void* workspace,
+                                       size_t workspace_bytes, ov_stream_t stream) {
+    if (!t || !x || !saved_inputs || !workspace || B <= 0 || L <= 0) return OV_ERR_INVALID;
+    if (tower_fp8(t)) return OV_ERR_UNSUPPORTED;                   // the backward differentiates the bf16 path
+    if (workspace_bytes < ov_tower_workspace_bytes(t, B, L)) return OV_ERR_WORKSPACE;
+    if (((uintptr_t)x | (uintptr_t)saved_inputs | (uintptr_t)workspace) & 15) return OV_ERR_INVALID;
+    const ov_tower_cfg& c = t->cfg;
+    const int D = c.width;
+    const int64_t M = (int64_t)B * L;
+    const int ldb = 3 * D > c.mlp_pad ? 3 * D : c.mlp_pad;
+    ov_bf16* h = (ov_bf16*)workspace;
+    ov_bf16* big = (ov_bf16*)((char*)workspace + align_up((size_t)M * D * 2, 256));
+    float* stats = (float*)((char*)big + align_up((size_t)M * ldb * 2, 256));
+    for (int i = 0; i < c.layers; ++i)
+        if (!t->set[i]) return OV_ERR_INVALID;
+    for (int i = 0; i < c.layers; ++i) {
+        hipError_t e = hipMemcpyAsync(saved_inputs + (size_t)i * M * D, x, (size_t)M * D * 2, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+        if (e != hipSuccess) return OV_ERR_HIP - (int)e;
+        const int rc = run_block(c, t->blocks[i], x, h, big, stats, B, L, stream, false);
+        if (rc) return rc;
+    }
+    return OV_OK;
+}
+
+extern "C" size_t ov_tower_backward_workspace_bytes(const ov_tower* t, int B, int L) {
+    if (!t) return 0;
+    return ov_block_backward_workspace_bytes(&t->cfg, B, L);
+}
+
+extern "C" int ov_tower_backward(const ov_tower* t, const ov_bf16* saved_inputs, ov_bf16* dx, const ov_block_grads* grads, int B, int L,
+                                 void* workspace, size_t workspace_bytes, ov_stream_t stream) {
+    if (!t || !saved_inputs || !dx || !grads || !workspace || B <= 0 || L <= 0) return OV_ERR_INVALID;
+    const ov_tower_cfg& c = t->cfg;
+    const int64_t M = (int64_t)B * L;
+    for (int i = 0; i < c.layers; ++i)
+        if (!t->set[i]) return OV_ERR_INVALID;
+    for (int i = c.layers - 1; i >= 0; --i) {                     // dx holds d(block output) on entry and d(block input) on exit
+        const int rc = ov_block_backward(&c, &t->blocks[i], saved_inputs + (size_t)i * M * c.width, dx, dx, &grads[i], B, L, workspace,
+                                         workspace_bytes, stream);
+        if (rc) return rc;
+    }
+    return OV_OK;
+}
+
 extern "C" size_t ov_vision_workspace_bytes(const ov_tower* t, const ov_vision_head* h, int B) {
     if (!t || !h || B <= 0 || h->patch_size <= 0) return 0;
     return vision_ws(t, h, B).total;
