@@ -1,0 +1,39 @@
+"""Time of one training step (forward with saved block inputs + InfoNCE + backward of both towers) on ONE GPU, L/14@224 by default.
+MODEL / BATCH environment variables select another preset / batch.  Not the headline metric (that is the forward step of bench.py)."""
+import os, sys, time, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from openvision_amd import preset, synth, training
+from openvision_amd.model import create_model
+from openvision_amd.loss import ClipLoss
+
+name = os.environ.get("MODEL", "vit-large-patch14-224")
+B = int(os.environ.get("BATCH", "256"))
+cfg = preset(name)
+m = create_model(cfg, device="cuda", state_dict=synth.make_state_dict(cfg))
+S = cfg["vision_cfg"]["image_size"]
+img = synth.make_images(B, S, seed=1).to("cuda")
+tok = synth.make_captions(B, seed=1).to("cuda")
+loss_fn = ClipLoss()
+
+def step():
+    m.zero_grad(set_to_none=True)
+    fi, ft, sc = training.clip_forward(m, img, tok)
+    loss = loss_fn(fi, ft, sc)
+    loss.backward()
+    return loss
+
+def fwd_only():
+    with torch.no_grad():
+        fi, ft = m.encode_image(img.to(torch.bfloat16), True), m.encode_text(tok, True)
+        return loss_fn(fi, ft, m.logit_scale.exp())
+
+for fn, label in ((fwd_only, "inference forward + loss"), (step, "training step (forward-saving + loss + backward)")):
+    fn(); torch.cuda.synchronize()
+    n = 3
+    t0 = time.perf_counter()
+    for _ in range(n):
+        out = fn()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / n * 1e3
+    print(f"{name} B={B} {label}: {ms:.1f} ms = {B / ms * 1e3:.0f} img/s; loss {float(out.detach()):.4f}; peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", flush=True)
