@@ -11,7 +11,8 @@
 // between waves: no atomics, results are deterministic.  All products are v_mfma_f32_32x32x16_bf16; P and dS are rounded to bf16
 // for the second products exactly as the forward rounds P.  The LDS image of each tensor is [d half][row][32 d] (64-byte rows):
 // it serves both the row-major 16-byte fragment reads (contraction over d) and ds_read_b64_tr_b16 (contraction over rows).
-// First version: correct and deterministic, not yet tuned (plain staging, no swizzle on the row-major reads).
+// 16-byte chunks are XOR-swizzled by (row >> 2) & 3 so that the ds_read_b128 lane groups are bank-conflict free.
+// First version: correct and deterministic, not yet tuned (plain staging, serial LDS waits).
 #include "common.h"
 
 namespace {
@@ -29,13 +30,22 @@ __device__ __forceinline__ bf16x8_t join8(u32x2_t a, u32x2_t b) {
     const u32x4_t w = {a[0], a[1], b[0], b[1]};
     return __builtin_bit_cast(bf16x8_t, w);
 }
-// A-operand fragment of X^T for one 16-row contraction step: rows addr.. and 8 rows further (offset 512 B), transposed by the
-// LDS unit.  Read and wait in ONE asm statement: the destination registers are complete when the statement ends.
-__device__ __forceinline__ bf16x8_t tr_frag(unsigned addr) {
-    u32x2_t a, b;
-    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:512\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(a), "=&v"(b) : "v"(addr) : "memory");
-    return join8(a, b);
+// A-operand fragments of X^T for one 32-row tile: (d half 0, rows 0-15), (half 1, rows 0-15), (half 0, rows 16-31), (half 1,
+// rows 16-31); each is two ds_read_b64_tr_b16 (rows r.. and 8 rows further, offset 512 B), transposed by the LDS unit.  All eight
+// reads and their wait sit in ONE asm statement: the destination registers are complete when the statement ends.
+struct TrFrags { bf16x8_t f[4]; };
+__device__ __forceinline__ TrFrags tr_frags(unsigned a0, unsigned b0, unsigned a1, unsigned b1) {   // d half 0 / 1; a: rows +0/+16, b: +8/+24
+    u32x2_t v0, v1, v2, v3, v4, v5, v6, v7;
+    asm volatile("ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %9 offset:512\n\t"
+                 "ds_read_b64_tr_b16 %2, %10\n\tds_read_b64_tr_b16 %3, %11 offset:512\n\t"
+                 "ds_read_b64_tr_b16 %4, %8 offset:1024\n\tds_read_b64_tr_b16 %5, %9 offset:1536\n\t"
+                 "ds_read_b64_tr_b16 %6, %10 offset:1024\n\tds_read_b64_tr_b16 %7, %11 offset:1536\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(v4), "=&v"(v5), "=&v"(v6), "=&v"(v7)
+                 : "v"(a0), "v"(b0), "v"(a1), "v"(b1) : "memory");
+    TrFrags t;
+    t.f[0] = join8(v0, v1); t.f[1] = join8(v2, v3); t.f[2] = join8(v4, v5); t.f[3] = join8(v6, v7);
+    return t;
 }
 __device__ __forceinline__ bf16x8_t pack8(const f32x16_t& t, int s) {
     const u32x4_t w = {pack_bf16x2(t[8 * s + 0], t[8 * s + 1]), pack_bf16x2(t[8 * s + 2], t[8 * s + 3]),
@@ -71,19 +81,27 @@ __global__ __launch_bounds__(640) void attn_bwd_hd64(const AttnBwdArgs a) {
             row = row < L ? row : L - 1;
             const int col = (dh * 4 + (pp & 3)) * 8;
             const ov_bf16* src = t < 3 ? qbase + (int64_t)row * a.ldq + t * HD + col : dbase + (int64_t)row * a.lddo + col;
-            *(u32x4_t*)(smem + t * img_bytes + p * 16) = *(const u32x4_t*)src;
+            // 16-byte chunk c of LDS row `pos` sits at chunk c ^ ((pos >> 2) & 3): the 16-lane groups of ds_read_b128 (rows 0-3, 12-15,
+            // 20-27 / 4-11, 16-19, 28-31) then cover all 16 slots of the 256-byte bank row; ds_read_b64_tr_b16 stays conflict-free
+            const int pos = pp >> 2;
+            *(u32x4_t*)(smem + t * img_bytes + dh * KC * 64 + pos * 64 + (((pp & 3) ^ ((pos >> 2) & 3)) << 4)) = *(const u32x4_t*)src;
         }
     }
     __syncthreads();
 
     // row-major fragment (contraction over d): row = tile * 32 + r, d = 16 st + 8 h2 .. + 8
     auto frag = [&](const char* img, int tile, int st) {
-        return *(const bf16x8_t*)(img + (st >> 1) * KC * 64 + (tile * 32 + r) * 64 + ((st & 1) * 16 + 8 * h2) * 2);
+        return *(const bf16x8_t*)(img + (st >> 1) * KC * 64 + (tile * 32 + r) * 64 + (((((st & 1) << 1) | h2) ^ ((r >> 2) & 3)) << 4));
     };
     const int vi = lane & 15, vg = (lane >> 4) & 1;
-    const unsigned tr_lane = (unsigned)((4 * h2 + (vi >> 2)) * 64 + (16 * vg + 4 * (vi & 3)) * 2);
-    auto tr_addr = [&](const char* img, int tile, int dh, int s) {
-        return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)img + (unsigned)(dh * KC * 64 + tile * 2048 + s * 1024) + tr_lane;
+    // transposing reads: lane row 4 h2 + (vi >> 2) (+ 8 k), logical chunk 2 vg + ((vi & 3) >> 1), 8-byte half vi & 1 of it; the chunk
+    // swizzle of that row is (h2 + 2 k) & 3: h2 for the row offsets 0 / 16 (immediates 0, 1024), h2 ^ 2 for 8 / 24 (512, 1536)
+    const unsigned tr_row = (unsigned)((4 * h2 + (vi >> 2)) * 64 + 8 * (vi & 1));
+    const unsigned tr_ch = (unsigned)(2 * vg + ((vi & 3) >> 1));
+    const unsigned tr_lane_a = tr_row + ((tr_ch ^ (unsigned)h2) << 4), tr_lane_b = tr_row + ((tr_ch ^ (unsigned)h2 ^ 2u) << 4);
+    auto tr_tile = [&](const char* img, int tile) {          // the four X^T fragments of rows tile*32 .. +32
+        const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)img + (unsigned)(tile * 2048);
+        return tr_frags(base + tr_lane_a, base + tr_lane_b, base + (unsigned)(KC * 64) + tr_lane_a, base + (unsigned)(KC * 64) + tr_lane_b);
     };
     const int nt = KC >> 5;                       // tiles = waves
 
@@ -134,7 +152,7 @@ __global__ __launch_bounds__(640) void attn_bwd_hd64(const AttnBwdArgs a) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const u32x4_t ov = *(const u32x4_t*)(op + 8 * c);
-                const u32x4_t dv = *(const u32x4_t*)(dp + 16 * c);
+                const u32x4_t dv = *(const u32x4_t*)(dp + ((c ^ ((query >> 2) & 3)) << 4));
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     delta = fmaf(bf16lo_to_f32(ov[e]), bf16lo_to_f32(dv[e]), delta);
@@ -164,10 +182,11 @@ __global__ __launch_bounds__(640) void attn_bwd_hd64(const AttnBwdArgs a) {
                 s[t] = p * (dp[t] - delta);                      // dS^T
             }
             const bf16x8_t b0 = pack8(s, 0), b1 = pack8(s, 1);
-            dq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(tr_addr(kimg, j, 0, 0)), b0, dq0, 0, 0, 0);
-            dq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(tr_addr(kimg, j, 1, 0)), b0, dq1, 0, 0, 0);
-            dq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(tr_addr(kimg, j, 0, 1)), b1, dq0, 0, 0, 0);
-            dq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(tr_addr(kimg, j, 1, 1)), b1, dq1, 0, 0, 0);
+            const TrFrags kt = tr_tile(kimg, j);
+            dq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt.f[0], b0, dq0, 0, 0, 0);
+            dq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt.f[1], b0, dq1, 0, 0, 0);
+            dq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt.f[2], b1, dq0, 0, 0, 0);
+            dq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt.f[3], b1, dq1, 0, 0, 0);
         }
         if (query < L) {                                         // rows d = 8 g + 4 h2 + e (dq0), + 32 (dq1)
             ov_bf16* op = a.dqkv + ((int64_t)b * L + query) * a.lddq + h * 64 + 4 * h2;
@@ -209,14 +228,16 @@ __global__ __launch_bounds__(640) void attn_bwd_hd64(const AttnBwdArgs a) {
                 dp[t] = p * (dp[t] - dlt[q]);                    // dS
             }
             const bf16x8_t p0 = pack8(s, 0), p1 = pack8(s, 1), g0 = pack8(dp, 0), g1 = pack8(dp, 1);
-            dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(tr_addr(dimg, i, 0, 0)), p0, dv0, 0, 0, 0);
-            dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(tr_addr(dimg, i, 1, 0)), p0, dv1, 0, 0, 0);
-            dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(tr_addr(dimg, i, 0, 1)), p1, dv0, 0, 0, 0);
-            dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(tr_addr(dimg, i, 1, 1)), p1, dv1, 0, 0, 0);
-            dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(tr_addr(qimg, i, 0, 0)), g0, dk0, 0, 0, 0);
-            dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(tr_addr(qimg, i, 1, 0)), g0, dk1, 0, 0, 0);
-            dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(tr_addr(qimg, i, 0, 1)), g1, dk0, 0, 0, 0);
-            dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(tr_addr(qimg, i, 1, 1)), g1, dk1, 0, 0, 0);
+            const TrFrags dt = tr_tile(dimg, i);
+            dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dt.f[0], p0, dv0, 0, 0, 0);
+            dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dt.f[1], p0, dv1, 0, 0, 0);
+            dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dt.f[2], p1, dv0, 0, 0, 0);
+            dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dt.f[3], p1, dv1, 0, 0, 0);
+            const TrFrags qt = tr_tile(qimg, i);
+            dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt.f[0], g0, dk0, 0, 0, 0);
+            dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt.f[1], g0, dk1, 0, 0, 0);
+            dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt.f[2], g1, dk0, 0, 0, 0);
+            dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt.f[3], g1, dk1, 0, 0, 0);
         }
         if (key < L) {
             ov_bf16* kp = a.dqkv + ((int64_t)b * L + key) * a.lddq + HD + h * 64 + 4 * h2;

@@ -117,8 +117,12 @@ def encode_image(model, image: torch.Tensor, normalize: bool = True) -> torch.Te
         raise _lib.OvhipError("training path: ln_pre is Identity for OpenVision towers")
     p = v.patch_size[0]
     w = v.conv1.weight
-    x = F.conv2d(image.float(), w.float(), None, stride=p)                                      # :610-612 (no bias)
-    x = x.reshape(x.shape[0], x.shape[1], -1).permute(0, 2, 1)
+    # conv1 (:610-612, stride = kernel, no bias) as patch rows times W^T: the same sums as F.conv2d, and a plain GEMM for autograd
+    # (MIOpen's fp32 convolution path costs tens of ms per step at this shape)
+    bsz, _, hh, ww = image.shape
+    gh, gw = hh // p, ww // p
+    patches = image.float().reshape(bsz, 3, gh, p, gw, p).permute(0, 2, 4, 1, 3, 5).reshape(bsz, gh * gw, 3 * p * p)
+    x = patches @ w.float().reshape(w.shape[0], -1).t()
     cls = v.class_embedding.float().expand(x.shape[0], 1, -1)
     x = torch.cat([cls, x], dim=1) + v.positional_embedding.float()                            # :615-617
     x = tower_forward(v.transformer, x)
