@@ -251,10 +251,13 @@ int ov_layernorm_backward(const ov_bf16* x, int64_t ldx, const float* gamma, con
 
 /* Backward of ov_attention (unmasked softmax attention of nn.MultiheadAttention, transformer.py:225,239-252): from the packed
  * qkv [B*L, 3*H*64], the forward output out [B*L, H*64] and the upstream gradient dout, writes dqkv [B*L, 3*H*64] = (dQ | dK | dV).
- * The row log-sum-exp is recomputed (the forward keeps none).  head_dim 64 and L <= 288 (a head's Q, K, V, dO resident in LDS);
- * OV_ERR_UNSUPPORTED otherwise.  Deterministic. */
+ * The row log-sum-exp is recomputed (the forward keeps none).  head_dim 64 only (OV_ERR_UNSUPPORTED otherwise).  L <= 288: one
+ * kernel with the head resident in LDS, no workspace; longer sequences: two streaming kernels and a workspace of
+ * ov_attention_backward_workspace_bytes (row lse and delta).  Deterministic. */
+size_t ov_attention_backward_workspace_bytes(int B, int L, int H);
 int ov_attention_backward(const ov_bf16* qkv, int64_t ld_qkv, const ov_bf16* out, int64_t ld_out, const ov_bf16* dout, int64_t ld_dout,
-                          ov_bf16* dqkv, int64_t ld_dqkv, int B, int L, int H, int hd, float scale, ov_stream_t stream);
+                          ov_bf16* dqkv, int64_t ld_dqkv, int B, int L, int H, int hd, float scale, void* workspace,
+                          size_t workspace_bytes, ov_stream_t stream);
 
 /* da = dh * gelu'(a) on the pre-activation a [rows, N] (tanh_form = 0: exact erf GELU, vision; 1: tanh form, text).  N % 8 == 0.
  * h_out (optional) receives gelu(a).  da may alias dh and h_out may alias a (element-wise, in place). */
@@ -335,7 +338,7 @@ int       ov_tower_forward(const ov_tower* t, ov_bf16* x, int B, int L, void* wo
  * c_fc pre-activation are recomputed with the forward kernels, then ov_gelu_backward / ov_linear_backward / ov_layernorm_backward /
  * ov_attention_backward run the chain rule.  `w` holds the module's own weights (no LN fold: qkv_colsum == fc_colsum == NULL,
  * qkv_b / fc_b the module biases).  Gradients: weights bf16 [out, in] (same layout as the weights), biases and LN parameters fp32;
- * all written (not accumulated).  dx may alias dy.  head_dim 64, mlp == mlp_pad, L <= 288; OV_ERR_UNSUPPORTED otherwise. */
+ * all written (not accumulated).  dx may alias dy.  head_dim 64, mlp == mlp_pad; OV_ERR_UNSUPPORTED otherwise. */
 typedef struct {
     float *ln1_w, *ln1_b;          /* [D] */
     ov_bf16* qkv_w; float* qkv_b;  /* [3D, D], [3D] */

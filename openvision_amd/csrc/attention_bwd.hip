@@ -3,7 +3,8 @@
 // The reference obtains it from autograd through nn.MultiheadAttention (open_clip/transformer.py:225,239-252; torch
 // nn/functional.py scaled-dot-product path).  With S = scale Q K^T, P = softmax(S), O = P V and an upstream dO:
 //     dV = P^T dO,   dP = dO V^T,   dS = P * (dP - delta),  delta[q] = sum_d dO[q,d] O[q,d],   dQ = scale dS K,   dK = scale dS^T Q.
-// One workgroup per (image, head); Q, K, V and dO of the head live in LDS (L <= 288), every wave owns one 32-row tile:
+// L <= 288: one workgroup per (image, head); Q, K, V and dO of the head live in LDS, every wave owns one 32-row tile
+// (longer sequences: the two streaming kernels at the end of this file, same tile arithmetic):
 //   pass 1  (wave = query tile)  log-sum-exp of its rows (the forward does not keep it) and delta        -> LDS
 //   pass 2  (wave = query tile)  S^T, dP^T tiles against every key tile, dQ^T += K^T dS^T                -> dQ
 //   pass 3  (wave = key tile)    S, dP tiles against every query tile, dV^T += dO^T P, dK^T += Q^T dS   -> dK, dV
@@ -257,13 +258,273 @@ __global__ __launch_bounds__(640) void attn_bwd_hd64(const AttnBwdArgs a) {
     }
 }
 
+
+// ---- long sequences (L > 288: S/8@384 has 2305 tokens): two streaming kernels with the same tile arithmetic ---------------------
+// A workgroup owns eight 32-row tiles (its fragments come straight from global memory into registers) and streams the OTHER side
+// through LDS in 256-row chunks of two images (64 KiB):
+//   attn_bwd_stream_q   own = query tiles; chunks of K (pass 1: lse) then K and V (pass 2: dQ); writes lse, delta to global
+//   attn_bwd_stream_kv  own = key tiles; chunks of Q and dO with their lse / delta; writes dK, dV
+constexpr int CH = 256;                       // chunk rows
+
+struct ChunkLds {
+    char* img0; char* img1; float* lse; float* dlt;
+};
+__device__ __forceinline__ ChunkLds chunk_lds(char* smem) {
+    ChunkLds c;
+    c.img0 = smem; c.img1 = smem + CH * 128; c.lse = (float*)(smem + 2 * CH * 128); c.dlt = c.lse + CH;
+    return c;
+}
+// stage rows [row0, row0 + 256) (clamped to L - 1) of two [L, 64] column blocks of the same row pitch into the two images
+__device__ __forceinline__ void stage_chunk(char* img0, char* img1, const ov_bf16* src0, const ov_bf16* src1, int64_t ld0, int64_t ld1,
+                                            int row0, int L, int tid, int nthreads, int nimg) {
+    for (int q = tid; q < nimg * CH * 8; q += nthreads) {
+        const int t = q / (CH * 8), p = q - t * CH * 8;
+        const int dh = p / (CH * 4), pp = p - dh * CH * 4;
+        const int pos = pp >> 2;
+        int row = row0 + pos;
+        row = row < L ? row : L - 1;
+        const int col = (dh * 4 + (pp & 3)) * 8;
+        const ov_bf16* src = t == 0 ? src0 + (int64_t)row * ld0 + col : src1 + (int64_t)row * ld1 + col;
+        *(u32x4_t*)((t == 0 ? img0 : img1) + dh * CH * 64 + pos * 64 + (((pp & 3) ^ ((pos >> 2) & 3)) << 4)) = *(const u32x4_t*)src;
+    }
+}
+
+struct AttnBwdSArgs {
+    AttnBwdArgs a;
+    float* lse;                               // [B*H, Lpad] log2-domain row lse
+    float* dlt;                               // [B*H, Lpad]
+    int Lpad, nblk;
+};
+
+#define OV_CHUNK_HELPERS()                                                                                                            \
+    auto frag = [&](const char* img, int tile, int st) {                                                                              \
+        return *(const bf16x8_t*)(img + (st >> 1) * CH * 64 + (tile * 32 + r) * 64 + (((((st & 1) << 1) | h2) ^ ((r >> 2) & 3)) << 4)); \
+    };                                                                                                                                \
+    const int vi = lane & 15, vg = (lane >> 4) & 1;                                                                                   \
+    const unsigned tr_row = (unsigned)((4 * h2 + (vi >> 2)) * 64 + 8 * (vi & 1));                                                     \
+    const unsigned tr_ch = (unsigned)(2 * vg + ((vi & 3) >> 1));                                                                      \
+    const unsigned tr_lane_a = tr_row + ((tr_ch ^ (unsigned)h2) << 4), tr_lane_b = tr_row + ((tr_ch ^ (unsigned)h2 ^ 2u) << 4);     \
+    auto tr_tile = [&](const char* img, int tile) {                                                                                   \
+        const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)img + (unsigned)(tile * 2048);      \
+        return tr_frags(base + tr_lane_a, base + tr_lane_b, base + (unsigned)(CH * 64) + tr_lane_a, base + (unsigned)(CH * 64) + tr_lane_b); \
+    };
+
+// this lane's B-operand fragments of row `row` (clamped) of a [L, 64] column block: d = 16 st + 8 h2 .. + 8
+__device__ __forceinline__ void load_own(bf16x8_t (&f)[4], const ov_bf16* base, int64_t ld, int row, int h2) {
+#pragma unroll
+    for (int st = 0; st < 4; ++st) f[st] = *(const bf16x8_t*)(base + (int64_t)row * ld + 16 * st + 8 * h2);
+}
+
+__global__ __launch_bounds__(512) void attn_bwd_stream_q(const AttnBwdSArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const AttnBwdArgs& a = g.a;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h2 = lane >> 5;
+    const int L = a.L, HD = a.H * 64;
+    const int bh = blockIdx.x / g.nblk, blk = blockIdx.x - bh * g.nblk;
+    const int b = bh / a.H, h = bh - b * a.H;
+    const ChunkLds c = chunk_lds(smem);
+    OV_CHUNK_HELPERS()
+    const ov_bf16* qbase = a.qkv + (int64_t)b * L * a.ldq + h * 64;
+    const ov_bf16* dbase = a.dout + (int64_t)b * L * a.lddo + h * 64;
+    const int query = blk * CH + wave * 32 + r;
+    const int qrow = query < L ? query : L - 1;
+    bf16x8_t qB[4], dB[4];
+    load_own(qB, qbase, a.ldq, qrow, h2);
+    load_own(dB, dbase, a.lddo, qrow, h2);
+    const int nchunk = (L + CH - 1) / CH;
+
+    // pass 1: lse over all keys
+    float m = -INFINITY, l = 0.f;
+    for (int ck = 0; ck < nchunk; ++ck) {
+        __syncthreads();
+        stage_chunk(c.img0, c.img1, qbase + HD, qbase + HD, a.ldq, a.ldq, ck * CH, L, tid, blockDim.x, 1);
+        __syncthreads();
+        const int ntile = (min(L - ck * CH, CH) + 31) >> 5;
+        for (int j = 0; j < ntile; ++j) {
+            f32x16_t s;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) s[t] = 0.f;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(c.img0, j, st), qB[st], s, 0, 0, 0);
+            float mx = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int key = ck * CH + j * 32 + (t & 3) + 8 * (t >> 2) + 4 * h2;
+                s[t] = key < L ? s[t] * a.scale_log2 : -INFINITY;
+                mx = fmaxf(mx, s[t]);
+            }
+            if (mx > -INFINITY) {
+                const float mn = fmaxf(m, mx);
+                float ps = 0.f;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) ps += __builtin_amdgcn_exp2f(s[t] - mn);
+                l = l * (m > -INFINITY ? __builtin_amdgcn_exp2f(m - mn) : 0.f) + ps;
+                m = mn;
+            }
+        }
+    }
+    {
+        const float mo = swap_halves(m), lo = swap_halves(l);
+        const float mn = fmaxf(m, mo);
+        l = l * (m > -INFINITY ? __builtin_amdgcn_exp2f(m - mn) : 0.f) + lo * (mo > -INFINITY ? __builtin_amdgcn_exp2f(mo - mn) : 0.f);
+        m = mn;
+    }
+    const float lse2 = m + __builtin_amdgcn_logf(l);
+    float delta = 0.f;
+    {
+        const ov_bf16* op = a.out + ((int64_t)b * L + qrow) * a.ldo + h * 64 + 32 * h2;
+        const ov_bf16* dp = dbase + (int64_t)qrow * a.lddo + 32 * h2;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            const u32x4_t ov = *(const u32x4_t*)(op + 8 * cc);
+            const u32x4_t dv = *(const u32x4_t*)(dp + 8 * cc);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                delta = fmaf(bf16lo_to_f32(ov[e]), bf16lo_to_f32(dv[e]), delta);
+                delta = fmaf(bf16hi_to_f32(ov[e]), bf16hi_to_f32(dv[e]), delta);
+            }
+        }
+        delta += swap_halves(delta);
+    }
+    if (h2 == 0 && query < g.Lpad) { g.lse[(int64_t)bh * g.Lpad + query] = lse2; g.dlt[(int64_t)bh * g.Lpad + query] = delta; }
+
+    // pass 2: dQ
+    f32x16_t dq0, dq1;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) { dq0[t] = 0.f; dq1[t] = 0.f; }
+    for (int ck = 0; ck < nchunk; ++ck) {
+        __syncthreads();
+        stage_chunk(c.img0, c.img1, qbase + HD, qbase + 2 * HD, a.ldq, a.ldq, ck * CH, L, tid, blockDim.x, 2);
+        __syncthreads();
+        const int ntile = (min(L - ck * CH, CH) + 31) >> 5;
+        for (int j = 0; j < ntile; ++j) {
+            f32x16_t s, dp;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) { s[t] = 0.f; dp[t] = 0.f; }
+#pragma unroll
+            for (int st = 0; st < 4; ++st) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(c.img0, j, st), qB[st], s, 0, 0, 0);
+#pragma unroll
+            for (int st = 0; st < 4; ++st) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(c.img1, j, st), dB[st], dp, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int key = ck * CH + j * 32 + (t & 3) + 8 * (t >> 2) + 4 * h2;
+                const float p = key < L ? __builtin_amdgcn_exp2f(fmaf(s[t], a.scale_log2, -lse2)) : 0.f;
+                s[t] = p * (dp[t] - delta);
+            }
+            const bf16x8_t b0 = pack8(s, 0), b1 = pack8(s, 1);
+            const TrFrags kt = tr_tile(c.img0, j);
+            dq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt.f[0], b0, dq0, 0, 0, 0);
+            dq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt.f[1], b0, dq1, 0, 0, 0);
+            dq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt.f[2], b1, dq0, 0, 0, 0);
+            dq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt.f[3], b1, dq1, 0, 0, 0);
+        }
+    }
+    if (query < L) {
+        ov_bf16* op = a.dqkv + ((int64_t)b * L + query) * a.lddq + h * 64 + 4 * h2;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const u32x2_t w0 = {pack_bf16x2(dq0[4 * gq] * a.scale, dq0[4 * gq + 1] * a.scale), pack_bf16x2(dq0[4 * gq + 2] * a.scale, dq0[4 * gq + 3] * a.scale)};
+            const u32x2_t w1 = {pack_bf16x2(dq1[4 * gq] * a.scale, dq1[4 * gq + 1] * a.scale), pack_bf16x2(dq1[4 * gq + 2] * a.scale, dq1[4 * gq + 3] * a.scale)};
+            *(u32x2_t*)(op + 8 * gq) = w0;
+            *(u32x2_t*)(op + 32 + 8 * gq) = w1;
+        }
+    }
+}
+
+__global__ __launch_bounds__(512) void attn_bwd_stream_kv(const AttnBwdSArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const AttnBwdArgs& a = g.a;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h2 = lane >> 5;
+    const int L = a.L, HD = a.H * 64;
+    const int bh = blockIdx.x / g.nblk, blk = blockIdx.x - bh * g.nblk;
+    const int b = bh / a.H, h = bh - b * a.H;
+    const ChunkLds c = chunk_lds(smem);
+    OV_CHUNK_HELPERS()
+    const ov_bf16* qbase = a.qkv + (int64_t)b * L * a.ldq + h * 64;
+    const ov_bf16* dbase = a.dout + (int64_t)b * L * a.lddo + h * 64;
+    const int key = blk * CH + wave * 32 + r;
+    const int krow = key < L ? key : L - 1;
+    bf16x8_t kB[4], vB[4];
+    load_own(kB, qbase + HD, a.ldq, krow, h2);
+    load_own(vB, qbase + 2 * HD, a.ldq, krow, h2);
+    f32x16_t dk0, dk1, dv0, dv1;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) { dk0[t] = 0.f; dk1[t] = 0.f; dv0[t] = 0.f; dv1[t] = 0.f; }
+    const int nchunk = (L + CH - 1) / CH;
+    for (int ck = 0; ck < nchunk; ++ck) {
+        __syncthreads();
+        stage_chunk(c.img0, c.img1, qbase, dbase, a.ldq, a.lddo, ck * CH, L, tid, blockDim.x, 2);
+        for (int q = tid; q < CH; q += blockDim.x) {
+            const int qq = ck * CH + q;
+            const int qc = qq < g.Lpad ? qq : g.Lpad - 1;
+            c.lse[q] = g.lse[(int64_t)bh * g.Lpad + qc];
+            c.dlt[q] = g.dlt[(int64_t)bh * g.Lpad + qc];
+        }
+        __syncthreads();
+        const int ntile = (min(L - ck * CH, CH) + 31) >> 5;
+        for (int i = 0; i < ntile; ++i) {
+            f32x16_t s, dp;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) { s[t] = 0.f; dp[t] = 0.f; }
+#pragma unroll
+            for (int st = 0; st < 4; ++st) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(c.img0, i, st), kB[st], s, 0, 0, 0);
+#pragma unroll
+            for (int st = 0; st < 4; ++st) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(c.img1, i, st), vB[st], dp, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int ql = i * 32 + (t & 3) + 8 * (t >> 2) + 4 * h2;
+                const float p = ck * CH + ql < L ? __builtin_amdgcn_exp2f(fmaf(s[t], a.scale_log2, -c.lse[ql])) : 0.f;
+                s[t] = p;
+                dp[t] = p * (dp[t] - c.dlt[ql]);
+            }
+            const bf16x8_t p0 = pack8(s, 0), p1 = pack8(s, 1), g0 = pack8(dp, 0), g1 = pack8(dp, 1);
+            const TrFrags dt = tr_tile(c.img1, i);
+            dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dt.f[0], p0, dv0, 0, 0, 0);
+            dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dt.f[1], p0, dv1, 0, 0, 0);
+            dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dt.f[2], p1, dv0, 0, 0, 0);
+            dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dt.f[3], p1, dv1, 0, 0, 0);
+            const TrFrags qt = tr_tile(c.img0, i);
+            dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt.f[0], g0, dk0, 0, 0, 0);
+            dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt.f[1], g0, dk1, 0, 0, 0);
+            dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt.f[2], g1, dk0, 0, 0, 0);
+            dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt.f[3], g1, dk1, 0, 0, 0);
+        }
+    }
+    if (key < L) {
+        ov_bf16* kp = a.dqkv + ((int64_t)b * L + key) * a.lddq + HD + h * 64 + 4 * h2;
+        ov_bf16* vp = kp + HD;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const u32x2_t k0 = {pack_bf16x2(dk0[4 * gq] * a.scale, dk0[4 * gq + 1] * a.scale), pack_bf16x2(dk0[4 * gq + 2] * a.scale, dk0[4 * gq + 3] * a.scale)};
+            const u32x2_t k1 = {pack_bf16x2(dk1[4 * gq] * a.scale, dk1[4 * gq + 1] * a.scale), pack_bf16x2(dk1[4 * gq + 2] * a.scale, dk1[4 * gq + 3] * a.scale)};
+            const u32x2_t v0 = {pack_bf16x2(dv0[4 * gq], dv0[4 * gq + 1]), pack_bf16x2(dv0[4 * gq + 2], dv0[4 * gq + 3])};
+            const u32x2_t v1 = {pack_bf16x2(dv1[4 * gq], dv1[4 * gq + 1]), pack_bf16x2(dv1[4 * gq + 2], dv1[4 * gq + 3])};
+            *(u32x2_t*)(kp + 8 * gq) = k0;
+            *(u32x2_t*)(kp + 32 + 8 * gq) = k1;
+            *(u32x2_t*)(vp + 8 * gq) = v0;
+            *(u32x2_t*)(vp + 32 + 8 * gq) = v1;
+        }
+    }
+}
+#undef OV_CHUNK_HELPERS
+
 }  // namespace
+
+extern "C" size_t ov_attention_backward_workspace_bytes(int B, int L, int H) {
+    if (B <= 0 || L <= 0 || H <= 0 || L <= 288) return 0;       // the resident kernel needs none
+    const int64_t lpad = (int64_t)(L + CH - 1) / CH * CH;
+    return (size_t)2 * B * H * lpad * sizeof(float);
+}
 
 extern "C" int ov_attention_backward(const ov_bf16* qkv, int64_t ld_qkv, const ov_bf16* out, int64_t ld_out, const ov_bf16* dout,
                                      int64_t ld_dout, ov_bf16* dqkv, int64_t ld_dqkv, int B, int L, int H, int hd, float scale,
-                                     ov_stream_t stream) {
+                                     void* workspace, size_t workspace_bytes, ov_stream_t stream) {
     if (!qkv || !out || !dout || !dqkv || B <= 0 || L <= 0 || H <= 0) return OV_ERR_INVALID;
-    if (hd != 64 || L > 288) return OV_ERR_UNSUPPORTED;          // K, V, Q, dO of a head resident in LDS
+    if (hd != 64) return OV_ERR_UNSUPPORTED;
     if (ld_qkv % 8 || ld_out % 8 || ld_dout % 8 || ld_dqkv % 8 || ld_qkv < 3 * H * 64 || ld_dqkv < 3 * H * 64 || ld_out < H * 64 ||
         ld_dout < H * 64)
         return OV_ERR_UNSUPPORTED;
@@ -273,14 +534,34 @@ extern "C" int ov_attention_backward(const ov_bf16* qkv, int64_t ld_qkv, const o
     a.qkv = qkv; a.ldq = ld_qkv; a.out = out; a.ldo = ld_out; a.dout = dout; a.lddo = ld_dout; a.dqkv = dqkv; a.lddq = ld_dqkv;
     a.L = L; a.H = H; a.KC = (L + 31) / 32 * 32;
     a.scale = scale; a.scale_log2 = scale * 1.4426950408889634f;
-    const size_t smem = (size_t)4 * a.KC * 128 + (size_t)2 * a.KC * sizeof(float);
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_hd64, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_stream_q, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_stream_kv, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         if (e != hipSuccess) return ov_hip(e);
         attr = true;
     }
-    hipLaunchKernelGGL(attn_bwd_hd64, dim3((unsigned)(B * H)), dim3((unsigned)(a.KC / 32 * 64)), smem, (hipStream_t)stream, a);
+    if (L <= 288) {                                             // Q, K, V, dO of a head resident in LDS
+        const size_t smem = (size_t)4 * a.KC * 128 + (size_t)2 * a.KC * sizeof(float);
+        hipLaunchKernelGGL(attn_bwd_hd64, dim3((unsigned)(B * H)), dim3((unsigned)(a.KC / 32 * 64)), smem, (hipStream_t)stream, a);
+        OV_LAUNCH_CHECK();
+        return OV_OK;
+    }
+    if (!workspace || ((uintptr_t)workspace & 15)) return OV_ERR_INVALID;
+    if (workspace_bytes < ov_attention_backward_workspace_bytes(B, L, H)) return OV_ERR_WORKSPACE;
+    AttnBwdSArgs g;
+    g.a = a;
+    g.nblk = (L + CH - 1) / CH;
+    g.Lpad = g.nblk * CH;
+    g.lse = (float*)workspace;
+    g.dlt = g.lse + (size_t)B * H * g.Lpad;
+    if ((int64_t)B * H * g.nblk > 0x7fffffffLL) return OV_ERR_UNSUPPORTED;
+    const size_t smem = (size_t)2 * CH * 128 + (size_t)2 * CH * sizeof(float);
+    const dim3 grid((unsigned)(B * H * g.nblk));
+    hipLaunchKernelGGL(attn_bwd_stream_q, grid, dim3(512), smem, (hipStream_t)stream, g);
+    OV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(attn_bwd_stream_kv, grid, dim3(512), smem, (hipStream_t)stream, g);
     OV_LAUNCH_CHECK();
     return OV_OK;
 }

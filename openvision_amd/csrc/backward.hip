@@ -19,7 +19,8 @@ extern "C" int ov_attention(const ov_bf16* qkv, int64_t ld_qkv, ov_bf16* out, in
                             ov_stream_t stream);
 extern "C" int ov_attention_backward(const ov_bf16* qkv, int64_t ld_qkv, const ov_bf16* out, int64_t ld_out, const ov_bf16* dout,
                                      int64_t ld_dout, ov_bf16* dqkv, int64_t ld_dqkv, int B, int L, int H, int hd, float scale,
-                                     ov_stream_t stream);
+                                     void* workspace, size_t workspace_bytes, ov_stream_t stream);
+extern "C" size_t ov_attention_backward_workspace_bytes(int B, int L, int H);
 extern "C" int ov_gemm_batched(const ov_bf16* A, int64_t lda, int64_t stride_a, const ov_bf16* W, int64_t ldw, int64_t stride_w,
                                ov_bf16* C, int64_t ldc, int64_t stride_c, int64_t M, int N, int K, int batch, ov_stream_t stream);
 
@@ -440,8 +441,9 @@ extern "C" int ov_gelu_backward(const ov_bf16* a, int64_t lda, const ov_bf16* dh
 // Activation recomputation: only the block input x is kept by the caller; ln_1, qkv, attention, x1, ln_2 and the c_fc
 // pre-activation are recomputed here with the forward's own kernels, then the chain rule runs back through the operators above.
 namespace {
-struct BlockBufs { ov_bf16 *n1, *qkv, *o, *x1, *n2, *a, *dh, *t1, *dx1, *dqkv; char* lin; char* ln; size_t lin_bytes, ln_bytes, total; };
-inline BlockBufs plan_block(const ov_tower_cfg* c, int64_t M, char* base) {
+struct BlockBufs { ov_bf16 *n1, *qkv, *o, *x1, *n2, *a, *dh, *t1, *dx1, *dqkv; char* lin; char* ln; char* att; size_t lin_bytes, ln_bytes, att_bytes, total; };
+inline BlockBufs plan_block(const ov_tower_cfg* c, int B, int L, char* base) {
+    const int64_t M = (int64_t)B * L;
     const int D = c->width, F = c->mlp_pad;
     BlockBufs b;
     size_t off = 0;
@@ -456,6 +458,7 @@ inline BlockBufs plan_block(const ov_tower_cfg* c, int64_t M, char* base) {
     lb = lb > l2 ? lb : l2; lb = lb > l3 ? lb : l3; lb = lb > l4 ? lb : l4;
     b.lin_bytes = lb; b.lin = take(lb);
     b.ln_bytes = ov_layernorm_backward_workspace_bytes(M, D); b.ln = take(b.ln_bytes);
+    b.att_bytes = ov_attention_backward_workspace_bytes(B, L, c->heads); b.att = take(b.att_bytes + 256);
     b.total = off;
     return b;
 }
@@ -467,13 +470,13 @@ inline bool block_cfg_ok(const ov_tower_cfg* c) {
 
 extern "C" size_t ov_block_backward_workspace_bytes(const ov_tower_cfg* cfg, int B, int L) {
     if (!block_cfg_ok(cfg) || B <= 0 || L <= 0) return 0;
-    return plan_block(cfg, (int64_t)B * L, nullptr).total;
+    return plan_block(cfg, B, L, nullptr).total;
 }
 
 extern "C" int ov_block_backward(const ov_tower_cfg* cfg, const ov_block_weights* w, const ov_bf16* x, const ov_bf16* dy, ov_bf16* dx,
                                  const ov_block_grads* g, int B, int L, void* workspace, size_t workspace_bytes, ov_stream_t stream) {
     if (!cfg || !w || !x || !dy || !dx || !g || !workspace || B <= 0 || L <= 0) return OV_ERR_INVALID;
-    if (!block_cfg_ok(cfg) || L > 288) return OV_ERR_UNSUPPORTED;             // head_dim 64, unpadded MLP, attention backward's L limit
+    if (!block_cfg_ok(cfg)) return OV_ERR_UNSUPPORTED;                        // head_dim 64, unpadded MLP
     if (w->qkv_colsum || w->fc_colsum) return OV_ERR_UNSUPPORTED;             // needs the module's own (unfolded) weights
     if (!w->ln1_w || !w->ln1_b || !w->qkv_w || !w->qkv_b || !w->out_w || !w->out_b || !w->ln2_w || !w->ln2_b || !w->fc_w || !w->fc_b ||
         !w->proj_w || !w->proj_b)
@@ -485,7 +488,7 @@ extern "C" int ov_block_backward(const ov_tower_cfg* cfg, const ov_block_weights
     const int64_t M = (int64_t)B * L;
     if (workspace_bytes < ov_block_backward_workspace_bytes(cfg, B, L)) return OV_ERR_WORKSPACE;
     if (((uintptr_t)workspace | (uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) return OV_ERR_INVALID;
-    const BlockBufs b = plan_block(cfg, M, (char*)workspace);
+    const BlockBufs b = plan_block(cfg, B, L, (char*)workspace);
     const float eps = cfg->ln_eps, scale = 0.125f;
     int rc;
 #define OV_TRY(call) do { if ((rc = (call)) != OV_OK) return rc; } while (0)
@@ -504,7 +507,7 @@ extern "C" int ov_block_backward(const ov_tower_cfg* cfg, const ov_block_weights
     OV_TRY(ov_layernorm_backward(b.x1, D, w->ln2_w, b.t1, D, dy, D, b.dx1, D, g->ln2_w, g->ln2_b, M, D, eps, b.ln, b.ln_bytes, stream)); // dx1 = dy + ...
     // ---- attention branch: x1 = x + out_proj(attn(qkv))
     OV_TRY(ov_linear_backward(b.dx1, D, b.o, D, w->out_w, D, M, D, D, b.t1, D, g->out_w, D, g->out_b, b.lin, b.lin_bytes, stream));     // t1 = d attention out
-    OV_TRY(ov_attention_backward(b.qkv, 3 * D, b.o, D, b.t1, D, b.dqkv, 3 * D, B, L, H, 64, scale, stream));
+    OV_TRY(ov_attention_backward(b.qkv, 3 * D, b.o, D, b.t1, D, b.dqkv, 3 * D, B, L, H, 64, scale, b.att, b.att_bytes, stream));
     OV_TRY(ov_linear_backward(b.dqkv, 3 * D, b.n1, D, w->qkv_w, D, M, 3 * D, D, b.t1, D, g->qkv_w, D, g->qkv_b, b.lin, b.lin_bytes, stream));  // t1 = d ln_1 out
     OV_TRY(ov_layernorm_backward(x, D, w->ln1_w, b.t1, D, b.dx1, D, dx, D, g->ln1_w, g->ln1_b, M, D, eps, b.ln, b.ln_bytes, stream));
 #undef OV_TRY

@@ -12,8 +12,8 @@ Opt-in: the inference entry points of ``openvision_amd.model`` never build a gra
     loss.backward()                                                         # .grad on every parameter, as with the reference
 
 Activation memory: the tower keeps one bf16 copy of every block's input (layers x B x L x D x 2 bytes; 3.2 GB for L/14 at B=256)
-and recomputes the inside of each block during its backward.  Limits of this first version: head_dim 64, mlp width % 64 == 0,
-sequence <= 288 tokens (the attention backward keeps a head in LDS) — L/14, B/16, Ti/16 and the text towers; S/8@384 is rejected.
+and recomputes the inside of each block during its backward.  Limits of this first version: head_dim 64 and mlp width % 64 == 0
+(Ti, S, B, L towers and their text towers; So400m / H with head_dim 72 / 80 are rejected).
 """
 from __future__ import annotations
 
@@ -53,8 +53,6 @@ class _TowerFn(torch.autograd.Function):
         if d != heads * 64 or mlp % 64 or d % 64:
             raise _lib.OvhipError("training path: head_dim 64 and mlp width % 64 == 0 are required")
         bsz, seq, _ = x.shape
-        if seq > 288:
-            raise _lib.OvhipError("training path: sequences longer than 288 tokens are not supported yet")
         cfg = _lib.TowerCfg(d, len(blocks), heads, mlp, mlp, int(b0.gelu_tanh), float(b0.ln_1.eps))
         handle = lib.ov_tower_create(C.byref(cfg))
         if not handle:

@@ -320,7 +320,8 @@ def test_gelu_backward_vs_oracle_and_golden(tanh):
     np.testing.assert_allclose(d.numpy(), want.numpy(), rtol=8e-3, atol=1e-3)
 
 
-@pytest.mark.parametrize("B,L,H", [(2, 257, 16), (3, 65, 2), (1, 33, 1), (2, 80, 12), (1, 288, 1), (2, 5, 1), (1, 1, 1), (2, 101, 3)])
+@pytest.mark.parametrize("B,L,H", [(2, 257, 16), (3, 65, 2), (1, 33, 1), (2, 80, 12), (1, 288, 1), (2, 5, 1), (1, 1, 1), (2, 101, 3),
+                                   (1, 289, 2), (2, 513, 3), (1, 2305, 6), (1, 1000, 1)])
 def test_attention_backward_vs_oracle(B, L, H):
     """dQ | dK | dV of the softmax attention vs the oracle's closed form on the same bf16 inputs.  P and dS are rounded to bf16 for
     the second products (as the forward rounds P) and the outputs are bf16: 2e-2 relative of the gradient scale."""
@@ -373,7 +374,8 @@ def _block_case(D, heads, mlp, B, L, tanh, seed):
     return names, sd, dev, x, dy
 
 
-@pytest.mark.parametrize("D,heads,mlp,B,L,tanh", [(192, 3, 768, 2, 101, False), (1024, 16, 4096, 2, 257, False), (768, 12, 3072, 3, 80, True)])
+@pytest.mark.parametrize("D,heads,mlp,B,L,tanh", [(192, 3, 768, 2, 101, False), (1024, 16, 4096, 2, 257, False), (768, 12, 3072, 3, 80, True),
+                                                  (384, 6, 1536, 1, 700, False)])
 def test_block_backward_vs_oracle(D, heads, mlp, B, L, tanh):
     """ov_block_backward (recompute + chain rule through the HIP operators) vs the oracle's closed-form block backward in fp32 on the
     same bf16 weights and inputs.  Every intermediate of the HIP path is bf16, so the comparison is relative to each gradient's
