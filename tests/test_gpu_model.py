@@ -3,6 +3,8 @@
 north_star tolerance: embeddings within 1e-3 cosine of the PyTorch (fp32) reference, top-k indices equal.
 The HIP path computes in bf16 (fp32 accumulate); the reference's own bf16 mode sits ~2e-5 (1-cos) from its
 fp32 mode on these weights (tests/test_oracle_golden.py::test_large_features)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -370,3 +372,83 @@ def test_training_step_gradients_tiny(tiny):
     with torch.no_grad():
         f = tiny.encode_image(img.to(DEV), normalize=True)
     assert not f.requires_grad and one_minus_cos(f.cpu(), fi.detach()) < 1e-3
+
+
+def test_training_loss_decreases_tiny(tiny):
+    """A few SGD steps on one fixed batch through the HIP forward/backward: the loss must go down steadily."""
+    from openvision_amd import training
+    from openvision_amd.loss import ClipLoss
+    cfg = preset("vit-tiny-patch16-160")
+    m = create_model(cfg, device=DEV, state_dict=synth.make_state_dict(cfg))
+    img, tok = synth.make_images(8, 160, seed=31).to(DEV), synth.make_captions(8, seed=31).to(DEV)
+    opt = torch.optim.SGD(m.parameters(), lr=0.05)
+    losses = []
+    for _ in range(8):
+        opt.zero_grad(set_to_none=True)
+        loss = ClipLoss()(*training.clip_forward(m, img, tok))
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0] - 0.05, losses
+    assert sum(b < a for a, b in zip(losses, losses[1:])) >= 6, losses
+
+
+def _ddp_rank(rank, ws, store, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    from openvision_amd import training
+    from openvision_amd.loss import ClipLoss
+    dist.init_process_group("gloo", init_method=f"file://{store}", rank=rank, world_size=ws)
+    cfg = preset("vit-tiny-patch16-160")
+    m = create_model(cfg, device=DEV, state_dict=synth.make_state_dict(cfg))
+    img, tok = synth.make_images(8, 160, seed=41), synth.make_captions(8, seed=41)
+    b = 8 // ws
+    li, lt = img[rank * b:(rank + 1) * b].to(DEV), tok[rank * b:(rank + 1) * b].to(DEV)
+    loss = ClipLoss(local_loss=True, gather_with_grad=True, rank=rank, world_size=ws)(*training.clip_forward(m, li, lt))
+    loss.backward()
+    out = {}
+    for name, p in m.named_parameters():                      # what DistributedDataParallel does: average the ranks' gradients
+        g = p.grad.detach().float().cpu()
+        dist.all_reduce(g)
+        out[name] = g / ws
+    lt_ = loss.detach().float().cpu()
+    dist.all_reduce(lt_)
+    q.put((rank, float(lt_ / ws), {k: v.numpy() for k, v in out.items()} if rank == 0 else None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_training_matches_single_process():
+    """The reference's training configuration (--local-loss --gather-with-grad, scripts/project/openvision/train.sh) on two ranks,
+    gradients averaged as DDP does, against one process on the whole batch: same loss and the same gradients up to bf16 noise."""
+    import tempfile
+    import torch.multiprocessing as mp
+    from openvision_amd import training
+    from openvision_amd.loss import ClipLoss
+    ctx = mp.get_context("spawn")
+    with tempfile.TemporaryDirectory() as d:
+        q = ctx.Queue()
+        ps = [ctx.Process(target=_ddp_rank, args=(r, 2, os.path.join(d, "store"), q)) for r in range(2)]
+        [p.start() for p in ps]
+        res = [q.get(timeout=600) for _ in range(2)]
+        [p.join(60) for p in ps]
+    dp_loss = res[0][1]
+    dp_grads = next(r[2] for r in res if r[2] is not None)
+    cfg = preset("vit-tiny-patch16-160")
+    m = create_model(cfg, device=DEV, state_dict=synth.make_state_dict(cfg))
+    img, tok = synth.make_images(8, 160, seed=41).to(DEV), synth.make_captions(8, seed=41).to(DEV)
+    loss = ClipLoss()(*training.clip_forward(m, img, tok))
+    loss.backward()
+    assert abs(float(loss.detach()) - dp_loss) < 2e-3
+    scale = max(float(p.grad.norm()) for p in m.parameters())
+    checked = 0
+    for name, p in m.named_parameters():
+        g, d_ = p.grad.float().cpu(), torch.from_numpy(dp_grads[name])
+        if float(g.norm()) < 1e-3 * scale:
+            continue
+        cos = float((g * d_).sum() / (g.norm() * d_.norm() + 1e-30))
+        assert cos > 0.995, (name, cos)
+        assert abs(float(d_.norm()) - float(g.norm())) < 0.03 * float(g.norm()), name
+        checked += 1
+    assert checked > 100
