@@ -347,18 +347,27 @@ typedef struct {
     ov_bf16* fc_w;  float* fc_b;   /* [mlp, D], [mlp] */
     ov_bf16* proj_w; float* proj_b;/* [D, mlp], [D] */
 } ov_block_grads;
+typedef struct {      /* optional forward intermediates kept for the backward (all three or none) */
+    const ov_bf16* qkv;        /* [B*L, 3D]  packed q | k | v */
+    const ov_bf16* attn_out;   /* [B*L, D]   attention output before out_proj */
+    const ov_bf16* x1;         /* [B*L, D]   x + attention branch */
+} ov_block_saved;
 size_t ov_block_backward_workspace_bytes(const ov_tower_cfg* cfg, int B, int L);
-int ov_block_backward(const ov_tower_cfg* cfg, const ov_block_weights* w, const ov_bf16* x, const ov_bf16* dy, ov_bf16* dx,
-                      const ov_block_grads* g, int B, int L, void* workspace, size_t workspace_bytes, ov_stream_t stream);
+int ov_block_backward(const ov_tower_cfg* cfg, const ov_block_weights* w, const ov_bf16* x, const ov_block_saved* saved /* or NULL */,
+                      const ov_bf16* dy, ov_bf16* dx, const ov_block_grads* g, int B, int L, void* workspace, size_t workspace_bytes,
+                      ov_stream_t stream);
 
-/* Training-side tower entry points.  ov_tower_forward_saving = ov_tower_forward on the caller's stream that also copies every
- * block's INPUT into saved_inputs [layers][B*L, D] (bf16 path only; the blocks must hold the module's own, unfolded weights for the
- * backward).  ov_tower_backward runs ov_block_backward over the layers in reverse: dx [B*L, D] holds d loss / d (tower output) on
- * entry and d loss / d (tower input) on return; grads[layer] receives that block's parameter gradients (written, not accumulated). */
-int    ov_tower_forward_saving(const ov_tower* t, ov_bf16* x, ov_bf16* saved_inputs, int B, int L, void* workspace,
-                               size_t workspace_bytes, ov_stream_t stream);
+/* Training-side tower entry points.  ov_tower_forward_saving = the tower forward on the caller's stream that keeps, per layer and
+ * token, [x | qkv | attention out | x1] (6 D bf16; `saved` holds ov_tower_saved_bytes: 19 GB for L/14 at batch 256 — sized for the
+ * 288 GB of an MI355X, so only the LayerNorm outputs and the c_fc pre-activation are recomputed).  bf16 path; the blocks must hold
+ * the module's own, unfolded weights.  ov_tower_backward runs ov_block_backward over the layers in reverse: dx [B*L, D] holds
+ * d loss / d (tower output) on entry and d loss / d (tower input) on return; grads[layer] receives that block's parameter gradients
+ * (written, not accumulated). */
+size_t ov_tower_saved_bytes(const ov_tower* t, int B, int L);
+int    ov_tower_forward_saving(const ov_tower* t, ov_bf16* x, ov_bf16* saved, int B, int L, void* workspace, size_t workspace_bytes,
+                               ov_stream_t stream);
 size_t ov_tower_backward_workspace_bytes(const ov_tower* t, int B, int L);
-int    ov_tower_backward(const ov_tower* t, const ov_bf16* saved_inputs, ov_bf16* dx, const ov_block_grads* grads, int B, int L,
+int    ov_tower_backward(const ov_tower* t, const ov_bf16* saved, ov_bf16* dx, const ov_block_grads* grads, int B, int L,
                          void* workspace, size_t workspace_bytes, ov_stream_t stream);
 
 typedef struct {      /* VisionTransformer front/back ends (OpenVision: no ln_pre, no conv bias) */

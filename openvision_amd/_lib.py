@@ -33,6 +33,10 @@ class BlockGrads(C.Structure):
                                         "proj_w", "proj_b")]
 
 
+class BlockSaved(C.Structure):
+    _fields_ = [(n, c_void_p) for n in ("qkv", "attn_out", "x1")]
+
+
 class BlockFp8(C.Structure):
     _fields_ = [(n, c_void_p) for n in ("qkv_w8", "qkv_s", "qkv_b", "out_w8", "out_s", "fc_w8", "fc_s", "fc_b", "proj_w8", "proj_s")]
 
@@ -108,7 +112,9 @@ SIGNATURES = {
     "ov_tower_backward_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
     "ov_tower_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "ov_block_backward_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
-    "ov_block_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "ov_block_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t,
+                                  c_void_p]),
+    "ov_tower_saved_bytes": (c_size_t, [c_void_p, c_int, c_int]),
     "ov_clip_loss_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p,
                                       c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "ov_profile_enable": (c_int, [C.c_uint, c_int]),

@@ -473,9 +473,11 @@ extern "C" size_t ov_block_backward_workspace_bytes(const ov_tower_cfg* cfg, int
     return plan_block(cfg, B, L, nullptr).total;
 }
 
-extern "C" int ov_block_backward(const ov_tower_cfg* cfg, const ov_block_weights* w, const ov_bf16* x, const ov_bf16* dy, ov_bf16* dx,
-                                 const ov_block_grads* g, int B, int L, void* workspace, size_t workspace_bytes, ov_stream_t stream) {
+extern "C" int ov_block_backward(const ov_tower_cfg* cfg, const ov_block_weights* w, const ov_bf16* x, const ov_block_saved* saved,
+                                 const ov_bf16* dy, ov_bf16* dx, const ov_block_grads* g, int B, int L, void* workspace,
+                                 size_t workspace_bytes, ov_stream_t stream) {
     if (!cfg || !w || !x || !dy || !dx || !g || !workspace || B <= 0 || L <= 0) return OV_ERR_INVALID;
+    if (saved && (!saved->qkv || !saved->attn_out || !saved->x1)) return OV_ERR_INVALID;
     if (!block_cfg_ok(cfg)) return OV_ERR_UNSUPPORTED;                        // head_dim 64, unpadded MLP
     if (w->qkv_colsum || w->fc_colsum) return OV_ERR_UNSUPPORTED;             // needs the module's own (unfolded) weights
     if (!w->ln1_w || !w->ln1_b || !w->qkv_w || !w->qkv_b || !w->out_w || !w->out_b || !w->ln2_w || !w->ln2_b || !w->fc_w || !w->fc_b ||
@@ -488,15 +490,20 @@ extern "C" int ov_block_backward(const ov_tower_cfg* cfg, const ov_block_weights
     const int64_t M = (int64_t)B * L;
     if (workspace_bytes < ov_block_backward_workspace_bytes(cfg, B, L)) return OV_ERR_WORKSPACE;
     if (((uintptr_t)workspace | (uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) return OV_ERR_INVALID;
-    const BlockBufs b = plan_block(cfg, B, L, (char*)workspace);
+    BlockBufs b = plan_block(cfg, B, L, (char*)workspace);
     const float eps = cfg->ln_eps, scale = 0.125f;
     int rc;
 #define OV_TRY(call) do { if ((rc = (call)) != OV_OK) return rc; } while (0)
-    // ---- recompute the forward's intermediates
+    // ---- the forward's intermediates: kept by ov_tower_forward_saving (qkv, attention output, x1) or recomputed; the two LayerNorm
+    //      outputs and the c_fc pre-activation are always recomputed (the forward fuses GELU into the c_fc epilogue)
     OV_TRY(ov_layernorm(x, OV_BF16, D, w->ln1_w, w->ln1_b, b.n1, OV_BF16, D, M, D, eps, stream));
-    OV_TRY(ov_gemm(b.n1, D, w->qkv_w, D, w->qkv_b, b.qkv, 3 * D, M, 3 * D, D, OV_EPI_BIAS, nullptr, 0, 0, 0, 0, stream));
-    OV_TRY(ov_attention(b.qkv, 3 * D, b.o, D, B, L, H, 64, scale, stream));
-    OV_TRY(ov_gemm(b.o, D, w->out_w, D, w->out_b, b.x1, D, M, D, D, OV_EPI_BIAS_RESIDUAL, x, D, 0, 0, 0, stream));
+    if (saved) {
+        b.qkv = const_cast<ov_bf16*>(saved->qkv); b.o = const_cast<ov_bf16*>(saved->attn_out); b.x1 = const_cast<ov_bf16*>(saved->x1);
+    } else {
+        OV_TRY(ov_gemm(b.n1, D, w->qkv_w, D, w->qkv_b, b.qkv, 3 * D, M, 3 * D, D, OV_EPI_BIAS, nullptr, 0, 0, 0, 0, stream));
+        OV_TRY(ov_attention(b.qkv, 3 * D, b.o, D, B, L, H, 64, scale, stream));
+        OV_TRY(ov_gemm(b.o, D, w->out_w, D, w->out_b, b.x1, D, M, D, D, OV_EPI_BIAS_RESIDUAL, x, D, 0, 0, 0, stream));
+    }
     OV_TRY(ov_layernorm(b.x1, OV_BF16, D, w->ln2_w, w->ln2_b, b.n2, OV_BF16, D, M, D, eps, stream));
     OV_TRY(ov_gemm(b.n2, D, w->fc_w, D, w->fc_b, b.a, F, M, F, D, OV_EPI_BIAS, nullptr, 0, 0, 0, 0, stream));
     // ---- MLP branch: y = x1 + c_proj(gelu(a))

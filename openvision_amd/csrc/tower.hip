@@ -427,30 +427,51 @@ extern "C" int ov_tower_forward(const ov_tower* t, ov_bf16* x, int B, int L, voi
 }
 
 // ---- training-side entry points: keep every block's input, run the blocks' backward in reverse -------------
-extern "C" int ov_block_backward(const ov_tower_cfg* cfg, const ov_block_weights* w, const ov_bf16* x, const ov_bf16* dy, ov_bf16* dx,
-                                 const ov_block_grads* g, int B, int L, void* workspace, size_t workspace_bytes, ov_stream_t stream);
+extern "C" int ov_block_backward(const ov_tower_cfg* cfg, const ov_block_weights* w, const ov_bf16* x, const ov_block_saved* saved,
+                                 const ov_bf16* dy, ov_bf16* dx, const ov_block_grads* g, int B, int L, void* workspace,
+                                 size_t workspace_bytes, ov_stream_t stream);
 extern "C" size_t ov_block_backward_workspace_bytes(const ov_tower_cfg* cfg, int B, int L);
 
-extern "C" int ov_tower_forward_saving(const ov_tower* t, ov_bf16* x, ov_bf16* saved_inputs, int B, int L, void* workspace,
+// saved activations of one layer: [x | qkv | attention out | x1], 6 D bf16 per token (288 GB of HBM: keep, do not recompute)
+extern "C" size_t ov_tower_saved_bytes(const ov_tower* t, int B, int L) {
+    if (!t || B <= 0 || L <= 0) return 0;
+    return (size_t)t->cfg.layers * B * L * 6 * t->cfg.width * sizeof(ov_bf16);
+}
+
+extern "C" int ov_tower_forward_saving(const ov_tower* t, ov_bf16* x, ov_bf16* saved, int B, int L, void* workspace,
                                        size_t workspace_bytes, ov_stream_t stream) {
-    if (!t || !x || !saved_inputs || !workspace || B <= 0 || L <= 0) return OV_ERR_INVALID;
+    if (!t || !x || !saved || !workspace || B <= 0 || L <= 0) return OV_ERR_INVALID;
     if (tower_fp8(t)) return OV_ERR_UNSUPPORTED;                   // the backward differentiates the bf16 path
     if (workspace_bytes < ov_tower_workspace_bytes(t, B, L)) return OV_ERR_WORKSPACE;
-    if (((uintptr_t)x | (uintptr_t)saved_inputs | (uintptr_t)workspace) & 15) return OV_ERR_INVALID;
+    if (((uintptr_t)x | (uintptr_t)saved | (uintptr_t)workspace) & 15) return OV_ERR_INVALID;
     const ov_tower_cfg& c = t->cfg;
-    const int D = c.width;
+    const int D = c.width, H = c.heads, hd = D / H;
     const int64_t M = (int64_t)B * L;
     const int ldb = 3 * D > c.mlp_pad ? 3 * D : c.mlp_pad;
     ov_bf16* h = (ov_bf16*)workspace;
     ov_bf16* big = (ov_bf16*)((char*)workspace + align_up((size_t)M * D * 2, 256));
-    float* stats = (float*)((char*)big + align_up((size_t)M * ldb * 2, 256));
+    const float scale = 1.0f / sqrtf((float)hd);
+    const int gelu = c.gelu_tanh ? OV_EPI_BIAS_GELU_TANH : OV_EPI_BIAS_GELU_ERF;
     for (int i = 0; i < c.layers; ++i)
-        if (!t->set[i]) return OV_ERR_INVALID;
+        if (!t->set[i] || t->blocks[i].qkv_colsum || t->blocks[i].fc_colsum) return OV_ERR_INVALID;   // the module's own weights
     for (int i = 0; i < c.layers; ++i) {
-        hipError_t e = hipMemcpyAsync(saved_inputs + (size_t)i * M * D, x, (size_t)M * D * 2, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+        const ov_block_weights& w = t->blocks[i];
+        ov_bf16* sx = saved + (size_t)i * M * 6 * D;
+        ov_bf16* sqkv = sx + (size_t)M * D;
+        ov_bf16* so = sqkv + (size_t)M * 3 * D;
+        ov_bf16* sx1 = so + (size_t)M * D;
+        hipError_t e = hipMemcpyAsync(sx, x, (size_t)M * D * 2, hipMemcpyDeviceToDevice, (hipStream_t)stream);
         if (e != hipSuccess) return OV_ERR_HIP - (int)e;
-        const int rc = run_block(c, t->blocks[i], x, h, big, stats, B, L, stream, false);
-        if (rc) return rc;
+        int rc;
+        // the same operator sequence as run_block, with qkv / attention output / x1 written where the backward will read them
+        if ((rc = ov_layernorm(x, OV_BF16, D, w.ln1_w, w.ln1_b, h, OV_BF16, D, M, D, c.ln_eps, stream))) return rc;
+        if ((rc = ov_gemm(h, D, w.qkv_w, D, w.qkv_b, sqkv, 3 * D, M, 3 * D, D, OV_EPI_BIAS, nullptr, 0, 0, 0, 0, stream))) return rc;
+        if ((rc = ov_attention(sqkv, 3 * D, so, D, B, L, H, hd, scale, stream))) return rc;
+        if ((rc = ov_gemm(so, D, w.out_w, D, w.out_b, sx1, D, M, D, D, OV_EPI_BIAS_RESIDUAL, x, D, 0, 0, 0, stream))) return rc;
+        if ((rc = ov_layernorm(sx1, OV_BF16, D, w.ln2_w, w.ln2_b, h, OV_BF16, D, M, D, c.ln_eps, stream))) return rc;
+        if ((rc = ov_gemm(h, D, w.fc_w, D, w.fc_b, big, ldb, M, c.mlp_pad, D, gelu, nullptr, 0, 0, 0, 0, stream))) return rc;
+        if ((rc = ov_gemm(big, ldb, w.proj_w, c.mlp_pad, w.proj_b, x, D, M, D, c.mlp_pad, OV_EPI_BIAS_RESIDUAL, sx1, D, 0, 0, 0, stream)))
+            return rc;
     }
     return OV_OK;
 }
@@ -460,16 +481,21 @@ extern "C" size_t ov_tower_backward_workspace_bytes(const ov_tower* t, int B, in
     return ov_block_backward_workspace_bytes(&t->cfg, B, L);
 }
 
-extern "C" int ov_tower_backward(const ov_tower* t, const ov_bf16* saved_inputs, ov_bf16* dx, const ov_block_grads* grads, int B, int L,
+extern "C" int ov_tower_backward(const ov_tower* t, const ov_bf16* saved, ov_bf16* dx, const ov_block_grads* grads, int B, int L,
                                  void* workspace, size_t workspace_bytes, ov_stream_t stream) {
-    if (!t || !saved_inputs || !dx || !grads || !workspace || B <= 0 || L <= 0) return OV_ERR_INVALID;
+    if (!t || !saved || !dx || !grads || !workspace || B <= 0 || L <= 0) return OV_ERR_INVALID;
     const ov_tower_cfg& c = t->cfg;
+    const int D = c.width;
     const int64_t M = (int64_t)B * L;
     for (int i = 0; i < c.layers; ++i)
         if (!t->set[i]) return OV_ERR_INVALID;
     for (int i = c.layers - 1; i >= 0; --i) {                     // dx holds d(block output) on entry and d(block input) on exit
-        const int rc = ov_block_backward(&c, &t->blocks[i], saved_inputs + (size_t)i * M * c.width, dx, dx, &grads[i], B, L, workspace,
-                                         workspace_bytes, stream);
+        const ov_bf16* sx = saved + (size_t)i * M * 6 * D;
+        ov_block_saved sv;
+        sv.qkv = sx + (size_t)M * D;
+        sv.attn_out = sv.qkv + (size_t)M * 3 * D;
+        sv.x1 = sv.attn_out + (size_t)M * D;
+        const int rc = ov_block_backward(&c, &t->blocks[i], sx, &sv, dx, dx, &grads[i], B, L, workspace, workspace_bytes, stream);
         if (rc) return rc;
     }
     return OV_OK;

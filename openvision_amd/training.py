@@ -11,8 +11,9 @@ Opt-in: the inference entry points of ``openvision_amd.model`` never build a gra
     loss = ClipLoss(...)(img_f, txt_f, scale)                               # openvision_amd.loss.ClipLoss
     loss.backward()                                                         # .grad on every parameter, as with the reference
 
-Activation memory: the tower keeps one bf16 copy of every block's input (layers x B x L x D x 2 bytes; 3.2 GB for L/14 at B=256)
-and recomputes the inside of each block during its backward.  Limits of this first version: head_dim 64 and mlp width % 64 == 0
+Activation memory: the tower keeps, per layer and token, the block input, the packed qkv, the attention output and the mid-block
+residual (6 D bf16: 19 GB for L/14 at B=256, sized for the 288 GB of an MI355X); the LayerNorm outputs and the c_fc
+pre-activation are recomputed during the backward.  Limits of this first version: head_dim 64 and mlp width % 64 == 0
 (Ti, S, B, L towers and their text towers; So400m / H with head_dim 72 / 80 are rejected).
 """
 from __future__ import annotations
@@ -65,7 +66,7 @@ class _TowerFn(torch.autograd.Function):
                 bw = _lib.BlockWeights(*[C.c_void_p(t.data_ptr()) for t in ts], None, None)
                 check(lib.ov_tower_set_block(handle, i, C.byref(bw)), "ov_tower_set_block")
             xb = x.detach().to(torch.bfloat16).contiguous().clone()
-            saved = torch.empty(len(blocks), bsz * seq, d, dtype=torch.bfloat16, device=x.device)
+            saved = torch.empty(lib.ov_tower_saved_bytes(handle, bsz, seq) // 2, dtype=torch.bfloat16, device=x.device)
             nbytes = lib.ov_tower_workspace_bytes(handle, bsz, seq)
             ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=x.device)
             check(lib.ov_tower_forward_saving(handle, ptr(xb), ptr(saved), bsz, seq, ptr(ws), nbytes, stream_ptr()),

@@ -205,7 +205,7 @@ def block_backward(cfg, weights, x, dy, B, L):
     nb = lib.ov_block_backward_workspace_bytes(C.byref(cfg), B, L)
     assert nb > 0
     ws = torch.empty(nb + 256, dtype=torch.uint8, device=x.device)
-    check(lib.ov_block_backward(C.byref(cfg), C.byref(wst), ptr(x), ptr(dy), ptr(dx), C.byref(gst), B, L, ptr(ws), nb, stream_ptr()),
+    check(lib.ov_block_backward(C.byref(cfg), C.byref(wst), ptr(x), None, ptr(dy), ptr(dx), C.byref(gst), B, L, ptr(ws), nb, stream_ptr()),
           "ov_block_backward")
     return dx, grads
 
