@@ -6,8 +6,8 @@ sets (loss.py:52-61), then the fused HIP kernel computes the local ``[b, N]`` lo
 ``i + b*rank`` (loss.py:93-94,108-110) without materialising them.
 
 Gradients: when a feature tensor or ``logit_scale`` requires grad, the loss is an autograd node whose backward is the
-HIP kernel behind ``ov_clip_loss_backward`` (d loss / d features and d loss / d logit_scale; the towers themselves are
-forward-only in this build, so this is where a training step's backward starts).  The gathered-side terms are routed as
+HIP kernel behind ``ov_clip_loss_backward`` (d loss / d features and d loss / d logit_scale); ``openvision_amd.training``
+carries the gradient on through the towers.  The gathered-side terms are routed as
 ``gather_features`` does (loss.py:19-63): own chunk only, or summed over ranks (reduce-scatter) with ``gather_with_grad``.
 ``use_horovod`` is rejected (RCCL via torch.distributed is the only transport here).
 """

@@ -11,7 +11,8 @@ activations with fp32 accumulation, LayerNorm statistics / affine, biases and th
 Parameters stay ordinary ``nn.Parameter``s (fp32 by default) so ``load_state_dict`` / ``.to()`` / ``.float()``
 behave as usual; bf16 device copies in the kernels' packed layout are rebuilt lazily when a parameter changes.
 
-Forward only (autograd is out of scope: SURVEY.md §8f row 4); outputs have ``requires_grad=False``.
+These entry points are the inference path: they never build an autograd graph and their outputs have ``requires_grad=False``;
+the training step with gradients is ``openvision_amd.training``.
 There is NO CPU / eager fallback: calling any forward with CPU tensors, or without libovhip.so, raises.
 """
 from __future__ import annotations
@@ -705,11 +706,11 @@ class CLIP(nn.Module):
         return image_features, text_features, scale
 
     def lock_image_tower(self, *a, **k):
-        raise NotImplementedError("training utilities are outside the forward-only path")
+        raise NotImplementedError("not provided: the training path (openvision_amd.training) differentiates every parameter")
 
     def set_grad_checkpointing(self, enable=True):
         if enable:
-            raise NotImplementedError("forward-only build: no autograd through the HIP kernels")
+            raise NotImplementedError("not needed: openvision_amd.training keeps per-layer activations and recomputes the rest itself")
 
 
 def logits(a: torch.Tensor, b: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
