@@ -250,11 +250,11 @@ int ov_layernorm_backward(const ov_bf16* x, int64_t ldx, const float* gamma, con
                           size_t workspace_bytes, ov_stream_t stream);
 
 /* Backward of ov_attention (unmasked softmax attention of nn.MultiheadAttention, transformer.py:225,239-252): from the packed
- * qkv [B*L, 3*H*64], the forward output out [B*L, H*64] and the upstream gradient dout, writes dqkv [B*L, 3*H*64] = (dQ | dK | dV).
- * The row log-sum-exp is recomputed (the forward keeps none).  head_dim 64 only (OV_ERR_UNSUPPORTED otherwise).  L <= 288: one
- * kernel with the head resident in LDS, no workspace; longer sequences: two streaming kernels and a workspace of
- * ov_attention_backward_workspace_bytes (row lse and delta).  Deterministic. */
-size_t ov_attention_backward_workspace_bytes(int B, int L, int H);
+ * qkv [B*L, 3*H*hd], the forward output out [B*L, H*hd] and the upstream gradient dout, writes dqkv [B*L, 3*H*hd] = (dQ | dK | dV).
+ * The row log-sum-exp is recomputed (the forward keeps none).  hd % 8 == 0, hd <= 96.  hd == 64 and L <= 288: one kernel with the
+ * head resident in LDS, no workspace; otherwise (long sequences; head dims 72 / 80 of So400m / H-14, zero-padded to 96 in LDS) two
+ * streaming kernels and a workspace of ov_attention_backward_workspace_bytes (row lse and delta).  Deterministic. */
+size_t ov_attention_backward_workspace_bytes(int B, int L, int H, int hd);
 int ov_attention_backward(const ov_bf16* qkv, int64_t ld_qkv, const ov_bf16* out, int64_t ld_out, const ov_bf16* dout, int64_t ld_dout,
                           ov_bf16* dqkv, int64_t ld_dqkv, int B, int L, int H, int hd, float scale, void* workspace,
                           size_t workspace_bytes, ov_stream_t stream);
@@ -338,7 +338,8 @@ int       ov_tower_forward(const ov_tower* t, ov_bf16* x, int B, int L, void* wo
  * c_fc pre-activation are recomputed with the forward kernels, then ov_gelu_backward / ov_linear_backward / ov_layernorm_backward /
  * ov_attention_backward run the chain rule.  `w` holds the module's own weights (no LN fold: qkv_colsum == fc_colsum == NULL,
  * qkv_b / fc_b the module biases).  Gradients: weights bf16 [out, in] (same layout as the weights), biases and LN parameters fp32;
- * all written (not accumulated).  dx may alias dy.  head_dim 64, mlp == mlp_pad; OV_ERR_UNSUPPORTED otherwise. */
+ * all written (not accumulated; rows / columns of the MLP padding, mlp .. mlp_pad, come out as zeros when the weights' padding is
+ * zero).  dx may alias dy.  width % 64 == 0, head_dim % 8 == 0 and <= 96, mlp_pad % 64 == 0; OV_ERR_UNSUPPORTED otherwise. */
 typedef struct {
     float *ln1_w, *ln1_b;          /* [D] */
     ov_bf16* qkv_w; float* qkv_b;  /* [3D, D], [3D] */

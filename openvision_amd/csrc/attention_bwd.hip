@@ -259,42 +259,75 @@ __global__ __launch_bounds__(640) void attn_bwd_hd64(const AttnBwdArgs a) {
 }
 
 
-// ---- long sequences (L > 288: S/8@384 has 2305 tokens): two streaming kernels with the same tile arithmetic ---------------------
+// ---- long sequences (L > 288: S/8@384 has 2305 tokens) and head dims 72 / 80: two streaming kernels, same tile arithmetic ---------
 // A workgroup owns eight 32-row tiles (its fragments come straight from global memory into registers) and streams the OTHER side
-// through LDS in 256-row chunks of two images (64 KiB):
+// through LDS in 256-row chunks of two images:
 //   attn_bwd_stream_q   own = query tiles; chunks of K (pass 1: lse) then K and V (pass 2: dQ); writes lse, delta to global
 //   attn_bwd_stream_kv  own = key tiles; chunks of Q and dO with their lse / delta; writes dK, dV
+// NDH = 32-wide d slices of an image (2: head_dim 64; 3: head dims 72 / 80 zero-padded to 96, So400m and H/14).
 constexpr int CH = 256;                       // chunk rows
-
-struct ChunkLds {
-    char* img0; char* img1; float* lse; float* dlt;
-};
-__device__ __forceinline__ ChunkLds chunk_lds(char* smem) {
-    ChunkLds c;
-    c.img0 = smem; c.img1 = smem + CH * 128; c.lse = (float*)(smem + 2 * CH * 128); c.dlt = c.lse + CH;
-    return c;
-}
-// stage rows [row0, row0 + 256) (clamped to L - 1) of two [L, 64] column blocks of the same row pitch into the two images
-__device__ __forceinline__ void stage_chunk(char* img0, char* img1, const ov_bf16* src0, const ov_bf16* src1, int64_t ld0, int64_t ld1,
-                                            int row0, int L, int tid, int nthreads, int nimg) {
-    for (int q = tid; q < nimg * CH * 8; q += nthreads) {
-        const int t = q / (CH * 8), p = q - t * CH * 8;
-        const int dh = p / (CH * 4), pp = p - dh * CH * 4;
-        const int pos = pp >> 2;
-        int row = row0 + pos;
-        row = row < L ? row : L - 1;
-        const int col = (dh * 4 + (pp & 3)) * 8;
-        const ov_bf16* src = t == 0 ? src0 + (int64_t)row * ld0 + col : src1 + (int64_t)row * ld1 + col;
-        *(u32x4_t*)((t == 0 ? img0 : img1) + dh * CH * 64 + pos * 64 + (((pp & 3) ^ ((pos >> 2) & 3)) << 4)) = *(const u32x4_t*)src;
-    }
-}
 
 struct AttnBwdSArgs {
     AttnBwdArgs a;
     float* lse;                               // [B*H, Lpad] log2-domain row lse
     float* dlt;                               // [B*H, Lpad]
-    int Lpad, nblk;
+    int Lpad, nblk, hd;
 };
+
+template <int NDH>
+struct Stream {
+    static constexpr int IMG = NDH * CH * 64;                     // bytes of one chunk image
+    // stage rows [row0, row0 + 256) (clamped to L - 1) of one or two [L, hd] column blocks into the images; columns >= hd are zeros
+    static __device__ __forceinline__ void stage(char* img0, char* img1, const ov_bf16* src0, const ov_bf16* src1, int64_t ld0, int64_t ld1,
+                                                 int row0, int L, int hd, int tid, int nthreads, int nimg) {
+        constexpr int NP = CH * NDH * 4;                          // 16-byte pieces per image
+        for (int q = tid; q < nimg * NP; q += nthreads) {
+            const int t = q / NP, p = q - t * NP;
+            const int dh = p / (CH * 4), pp = p - dh * CH * 4;
+            const int pos = pp >> 2;
+            int row = row0 + pos;
+            row = row < L ? row : L - 1;
+            const int col = (dh * 4 + (pp & 3)) * 8;
+            u32x4_t v = {0u, 0u, 0u, 0u};
+            if (col < hd) v = *(const u32x4_t*)(t == 0 ? src0 + (int64_t)row * ld0 + col : src1 + (int64_t)row * ld1 + col);
+            *(u32x4_t*)((t == 0 ? img0 : img1) + dh * CH * 64 + pos * 64 + (((pp & 3) ^ ((pos >> 2) & 3)) << 4)) = v;
+        }
+    }
+    // this lane's B-operand fragments of row `row` of a [L, hd] column block: d = 16 st + 8 h2 .. + 8 (zeros past hd)
+    static __device__ __forceinline__ void load_own(bf16x8_t (&f)[2 * NDH], const ov_bf16* base, int64_t ld, int row, int h2, int hd) {
+#pragma unroll
+        for (int st = 0; st < 2 * NDH; ++st) {
+            u32x4_t v = {0u, 0u, 0u, 0u};
+            if (16 * st + 8 * h2 < hd) v = *(const u32x4_t*)(base + (int64_t)row * ld + 16 * st + 8 * h2);
+            f[st] = __builtin_bit_cast(bf16x8_t, v);
+        }
+    }
+    // store rows d = 32 dh + 8 g + 4 h2 + e of the accumulators (lane = output row of the tensor) scaled by `sc`
+    static __device__ __forceinline__ void store(ov_bf16* op, const f32x16_t (&acc)[NDH], float sc, int h2, int hd) {
+#pragma unroll
+        for (int dh = 0; dh < NDH; ++dh)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int d0 = 32 * dh + 8 * gq + 4 * h2;
+                if (d0 < hd) {
+                    const u32x2_t w = {pack_bf16x2(acc[dh][4 * gq] * sc, acc[dh][4 * gq + 1] * sc),
+                                       pack_bf16x2(acc[dh][4 * gq + 2] * sc, acc[dh][4 * gq + 3] * sc)};
+                    *(u32x2_t*)(op + d0) = w;
+                }
+            }
+    }
+};
+
+// two A-operand fragments (contraction steps 0 and 1) of one d slice of X^T for a 32-row tile; reads and wait in ONE asm statement
+__device__ __forceinline__ void tr_half(unsigned a0, unsigned b0, bf16x8_t& f0, bf16x8_t& f1) {
+    u32x2_t v0, v1, v2, v3;
+    asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %5 offset:512\n\t"
+                 "ds_read_b64_tr_b16 %2, %4 offset:1024\n\tds_read_b64_tr_b16 %3, %5 offset:1536\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(a0), "v"(b0) : "memory");
+    f0 = join8(v0, v1);
+    f1 = join8(v2, v3);
+}
 
 #define OV_CHUNK_HELPERS()                                                                                                            \
     auto frag = [&](const char* img, int tile, int st) {                                                                              \
@@ -304,42 +337,45 @@ struct AttnBwdSArgs {
     const unsigned tr_row = (unsigned)((4 * h2 + (vi >> 2)) * 64 + 8 * (vi & 1));                                                     \
     const unsigned tr_ch = (unsigned)(2 * vg + ((vi & 3) >> 1));                                                                      \
     const unsigned tr_lane_a = tr_row + ((tr_ch ^ (unsigned)h2) << 4), tr_lane_b = tr_row + ((tr_ch ^ (unsigned)h2 ^ 2u) << 4);     \
-    auto tr_tile = [&](const char* img, int tile) {                                                                                   \
+    /* acc[dh] += X^T(d slice dh, rows of `tile`) . T  with T packed as b0 (rows 0-15) / b1 (rows 16-31) */                           \
+    auto tr_mma = [&](const char* img, int tile, bf16x8_t b0, bf16x8_t b1, f32x16_t (&acc)[NDH]) {                                    \
         const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)img + (unsigned)(tile * 2048);      \
-        return tr_frags(base + tr_lane_a, base + tr_lane_b, base + (unsigned)(CH * 64) + tr_lane_a, base + (unsigned)(CH * 64) + tr_lane_b); \
+        _Pragma("unroll") for (int dh = 0; dh < NDH; ++dh) {                                                                          \
+            bf16x8_t f0, f1;                                                                                                          \
+            tr_half(base + (unsigned)(dh * CH * 64) + tr_lane_a, base + (unsigned)(dh * CH * 64) + tr_lane_b, f0, f1);                \
+            acc[dh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, b0, acc[dh], 0, 0, 0);                                              \
+            acc[dh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1, b1, acc[dh], 0, 0, 0);                                              \
+        }                                                                                                                             \
     };
 
-// this lane's B-operand fragments of row `row` (clamped) of a [L, 64] column block: d = 16 st + 8 h2 .. + 8
-__device__ __forceinline__ void load_own(bf16x8_t (&f)[4], const ov_bf16* base, int64_t ld, int row, int h2) {
-#pragma unroll
-    for (int st = 0; st < 4; ++st) f[st] = *(const bf16x8_t*)(base + (int64_t)row * ld + 16 * st + 8 * h2);
-}
-
+template <int NDH>
 __global__ __launch_bounds__(512) void attn_bwd_stream_q(const AttnBwdSArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef Stream<NDH> St;
     const AttnBwdArgs& a = g.a;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h2 = lane >> 5;
-    const int L = a.L, HD = a.H * 64;
+    const int L = a.L, hd = g.hd, HD = a.H * hd;
     const int bh = blockIdx.x / g.nblk, blk = blockIdx.x - bh * g.nblk;
     const int b = bh / a.H, h = bh - b * a.H;
-    const ChunkLds c = chunk_lds(smem);
+    char* img0 = smem;
+    char* img1 = smem + St::IMG;
     OV_CHUNK_HELPERS()
-    const ov_bf16* qbase = a.qkv + (int64_t)b * L * a.ldq + h * 64;
-    const ov_bf16* dbase = a.dout + (int64_t)b * L * a.lddo + h * 64;
+    const ov_bf16* qbase = a.qkv + (int64_t)b * L * a.ldq + h * hd;
+    const ov_bf16* dbase = a.dout + (int64_t)b * L * a.lddo + h * hd;
     const int query = blk * CH + wave * 32 + r;
     const int qrow = query < L ? query : L - 1;
-    bf16x8_t qB[4], dB[4];
-    load_own(qB, qbase, a.ldq, qrow, h2);
-    load_own(dB, dbase, a.lddo, qrow, h2);
+    bf16x8_t qB[2 * NDH], dB[2 * NDH];
+    St::load_own(qB, qbase, a.ldq, qrow, h2, hd);
+    St::load_own(dB, dbase, a.lddo, qrow, h2, hd);
     const int nchunk = (L + CH - 1) / CH;
 
     // pass 1: lse over all keys
     float m = -INFINITY, l = 0.f;
     for (int ck = 0; ck < nchunk; ++ck) {
         __syncthreads();
-        stage_chunk(c.img0, c.img1, qbase + HD, qbase + HD, a.ldq, a.ldq, ck * CH, L, tid, blockDim.x, 1);
+        St::stage(img0, img1, qbase + HD, qbase + HD, a.ldq, a.ldq, ck * CH, L, hd, tid, blockDim.x, 1);
         __syncthreads();
         const int ntile = (min(L - ck * CH, CH) + 31) >> 5;
         for (int j = 0; j < ntile; ++j) {
@@ -347,7 +383,7 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_q(const AttnBwdSArgs g) {
 #pragma unroll
             for (int t = 0; t < 16; ++t) s[t] = 0.f;
 #pragma unroll
-            for (int st = 0; st < 4; ++st) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(c.img0, j, st), qB[st], s, 0, 0, 0);
+            for (int st = 0; st < 2 * NDH; ++st) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(img0, j, st), qB[st], s, 0, 0, 0);
             float mx = -INFINITY;
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
@@ -373,11 +409,10 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_q(const AttnBwdSArgs g) {
     }
     const float lse2 = m + __builtin_amdgcn_logf(l);
     float delta = 0.f;
-    {
-        const ov_bf16* op = a.out + ((int64_t)b * L + qrow) * a.ldo + h * 64 + 32 * h2;
-        const ov_bf16* dp = dbase + (int64_t)qrow * a.lddo + 32 * h2;
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
+    {   // delta = sum_d dO[q, d] O[q, d]: the two lane halves take alternate 8-element chunks
+        const ov_bf16* op = a.out + ((int64_t)b * L + qrow) * a.ldo + h * hd;
+        const ov_bf16* dp = dbase + (int64_t)qrow * a.lddo;
+        for (int cc = h2; cc < (hd >> 3); cc += 2) {
             const u32x4_t ov = *(const u32x4_t*)(op + 8 * cc);
             const u32x4_t dv = *(const u32x4_t*)(dp + 8 * cc);
 #pragma unroll
@@ -391,12 +426,14 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_q(const AttnBwdSArgs g) {
     if (h2 == 0 && query < g.Lpad) { g.lse[(int64_t)bh * g.Lpad + query] = lse2; g.dlt[(int64_t)bh * g.Lpad + query] = delta; }
 
     // pass 2: dQ
-    f32x16_t dq0, dq1;
+    f32x16_t dq[NDH];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) { dq0[t] = 0.f; dq1[t] = 0.f; }
+    for (int dh = 0; dh < NDH; ++dh)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) dq[dh][t] = 0.f;
     for (int ck = 0; ck < nchunk; ++ck) {
         __syncthreads();
-        stage_chunk(c.img0, c.img1, qbase + HD, qbase + 2 * HD, a.ldq, a.ldq, ck * CH, L, tid, blockDim.x, 2);
+        St::stage(img0, img1, qbase + HD, qbase + 2 * HD, a.ldq, a.ldq, ck * CH, L, hd, tid, blockDim.x, 2);
         __syncthreads();
         const int ntile = (min(L - ck * CH, CH) + 31) >> 5;
         for (int j = 0; j < ntile; ++j) {
@@ -404,65 +441,58 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_q(const AttnBwdSArgs g) {
 #pragma unroll
             for (int t = 0; t < 16; ++t) { s[t] = 0.f; dp[t] = 0.f; }
 #pragma unroll
-            for (int st = 0; st < 4; ++st) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(c.img0, j, st), qB[st], s, 0, 0, 0);
+            for (int st = 0; st < 2 * NDH; ++st) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(img0, j, st), qB[st], s, 0, 0, 0);
 #pragma unroll
-            for (int st = 0; st < 4; ++st) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(c.img1, j, st), dB[st], dp, 0, 0, 0);
+            for (int st = 0; st < 2 * NDH; ++st) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(img1, j, st), dB[st], dp, 0, 0, 0);
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
                 const int key = ck * CH + j * 32 + (t & 3) + 8 * (t >> 2) + 4 * h2;
                 const float p = key < L ? __builtin_amdgcn_exp2f(fmaf(s[t], a.scale_log2, -lse2)) : 0.f;
                 s[t] = p * (dp[t] - delta);
             }
-            const bf16x8_t b0 = pack8(s, 0), b1 = pack8(s, 1);
-            const TrFrags kt = tr_tile(c.img0, j);
-            dq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt.f[0], b0, dq0, 0, 0, 0);
-            dq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt.f[1], b0, dq1, 0, 0, 0);
-            dq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt.f[2], b1, dq0, 0, 0, 0);
-            dq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt.f[3], b1, dq1, 0, 0, 0);
+            tr_mma(img0, j, pack8(s, 0), pack8(s, 1), dq);
         }
     }
-    if (query < L) {
-        ov_bf16* op = a.dqkv + ((int64_t)b * L + query) * a.lddq + h * 64 + 4 * h2;
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            const u32x2_t w0 = {pack_bf16x2(dq0[4 * gq] * a.scale, dq0[4 * gq + 1] * a.scale), pack_bf16x2(dq0[4 * gq + 2] * a.scale, dq0[4 * gq + 3] * a.scale)};
-            const u32x2_t w1 = {pack_bf16x2(dq1[4 * gq] * a.scale, dq1[4 * gq + 1] * a.scale), pack_bf16x2(dq1[4 * gq + 2] * a.scale, dq1[4 * gq + 3] * a.scale)};
-            *(u32x2_t*)(op + 8 * gq) = w0;
-            *(u32x2_t*)(op + 32 + 8 * gq) = w1;
-        }
-    }
+    if (query < L) St::store(a.dqkv + ((int64_t)b * L + query) * a.lddq + h * hd, dq, a.scale, h2, hd);
 }
 
+template <int NDH>
 __global__ __launch_bounds__(512) void attn_bwd_stream_kv(const AttnBwdSArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef Stream<NDH> St;
     const AttnBwdArgs& a = g.a;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h2 = lane >> 5;
-    const int L = a.L, HD = a.H * 64;
+    const int L = a.L, hd = g.hd, HD = a.H * hd;
     const int bh = blockIdx.x / g.nblk, blk = blockIdx.x - bh * g.nblk;
     const int b = bh / a.H, h = bh - b * a.H;
-    const ChunkLds c = chunk_lds(smem);
+    char* img0 = smem;
+    char* img1 = smem + St::IMG;
+    float* lse_s = (float*)(smem + 2 * St::IMG);
+    float* dlt_s = lse_s + CH;
     OV_CHUNK_HELPERS()
-    const ov_bf16* qbase = a.qkv + (int64_t)b * L * a.ldq + h * 64;
-    const ov_bf16* dbase = a.dout + (int64_t)b * L * a.lddo + h * 64;
+    const ov_bf16* qbase = a.qkv + (int64_t)b * L * a.ldq + h * hd;
+    const ov_bf16* dbase = a.dout + (int64_t)b * L * a.lddo + h * hd;
     const int key = blk * CH + wave * 32 + r;
     const int krow = key < L ? key : L - 1;
-    bf16x8_t kB[4], vB[4];
-    load_own(kB, qbase + HD, a.ldq, krow, h2);
-    load_own(vB, qbase + 2 * HD, a.ldq, krow, h2);
-    f32x16_t dk0, dk1, dv0, dv1;
+    bf16x8_t kB[2 * NDH], vB[2 * NDH];
+    St::load_own(kB, qbase + HD, a.ldq, krow, h2, hd);
+    St::load_own(vB, qbase + 2 * HD, a.ldq, krow, h2, hd);
+    f32x16_t dk[NDH], dv[NDH];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) { dk0[t] = 0.f; dk1[t] = 0.f; dv0[t] = 0.f; dv1[t] = 0.f; }
+    for (int dh = 0; dh < NDH; ++dh)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) { dk[dh][t] = 0.f; dv[dh][t] = 0.f; }
     const int nchunk = (L + CH - 1) / CH;
     for (int ck = 0; ck < nchunk; ++ck) {
         __syncthreads();
-        stage_chunk(c.img0, c.img1, qbase, dbase, a.ldq, a.lddo, ck * CH, L, tid, blockDim.x, 2);
+        St::stage(img0, img1, qbase, dbase, a.ldq, a.lddo, ck * CH, L, hd, tid, blockDim.x, 2);
         for (int q = tid; q < CH; q += blockDim.x) {
             const int qq = ck * CH + q;
             const int qc = qq < g.Lpad ? qq : g.Lpad - 1;
-            c.lse[q] = g.lse[(int64_t)bh * g.Lpad + qc];
-            c.dlt[q] = g.dlt[(int64_t)bh * g.Lpad + qc];
+            lse_s[q] = g.lse[(int64_t)bh * g.Lpad + qc];
+            dlt_s[q] = g.dlt[(int64_t)bh * g.Lpad + qc];
         }
         __syncthreads();
         const int ntile = (min(L - ck * CH, CH) + 31) >> 5;
@@ -471,62 +501,63 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kv(const AttnBwdSArgs g) 
 #pragma unroll
             for (int t = 0; t < 16; ++t) { s[t] = 0.f; dp[t] = 0.f; }
 #pragma unroll
-            for (int st = 0; st < 4; ++st) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(c.img0, i, st), kB[st], s, 0, 0, 0);
+            for (int st = 0; st < 2 * NDH; ++st) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(img0, i, st), kB[st], s, 0, 0, 0);
 #pragma unroll
-            for (int st = 0; st < 4; ++st) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(c.img1, i, st), vB[st], dp, 0, 0, 0);
+            for (int st = 0; st < 2 * NDH; ++st) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(img1, i, st), vB[st], dp, 0, 0, 0);
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
                 const int ql = i * 32 + (t & 3) + 8 * (t >> 2) + 4 * h2;
-                const float p = ck * CH + ql < L ? __builtin_amdgcn_exp2f(fmaf(s[t], a.scale_log2, -c.lse[ql])) : 0.f;
+                const float p = ck * CH + ql < L ? __builtin_amdgcn_exp2f(fmaf(s[t], a.scale_log2, -lse_s[ql])) : 0.f;
                 s[t] = p;
-                dp[t] = p * (dp[t] - c.dlt[ql]);
+                dp[t] = p * (dp[t] - dlt_s[ql]);
             }
-            const bf16x8_t p0 = pack8(s, 0), p1 = pack8(s, 1), g0 = pack8(dp, 0), g1 = pack8(dp, 1);
-            const TrFrags dt = tr_tile(c.img1, i);
-            dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dt.f[0], p0, dv0, 0, 0, 0);
-            dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dt.f[1], p0, dv1, 0, 0, 0);
-            dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dt.f[2], p1, dv0, 0, 0, 0);
-            dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dt.f[3], p1, dv1, 0, 0, 0);
-            const TrFrags qt = tr_tile(c.img0, i);
-            dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt.f[0], g0, dk0, 0, 0, 0);
-            dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt.f[1], g0, dk1, 0, 0, 0);
-            dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt.f[2], g1, dk0, 0, 0, 0);
-            dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt.f[3], g1, dk1, 0, 0, 0);
+            tr_mma(img1, i, pack8(s, 0), pack8(s, 1), dv);
+            tr_mma(img0, i, pack8(dp, 0), pack8(dp, 1), dk);
         }
     }
     if (key < L) {
-        ov_bf16* kp = a.dqkv + ((int64_t)b * L + key) * a.lddq + HD + h * 64 + 4 * h2;
-        ov_bf16* vp = kp + HD;
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            const u32x2_t k0 = {pack_bf16x2(dk0[4 * gq] * a.scale, dk0[4 * gq + 1] * a.scale), pack_bf16x2(dk0[4 * gq + 2] * a.scale, dk0[4 * gq + 3] * a.scale)};
-            const u32x2_t k1 = {pack_bf16x2(dk1[4 * gq] * a.scale, dk1[4 * gq + 1] * a.scale), pack_bf16x2(dk1[4 * gq + 2] * a.scale, dk1[4 * gq + 3] * a.scale)};
-            const u32x2_t v0 = {pack_bf16x2(dv0[4 * gq], dv0[4 * gq + 1]), pack_bf16x2(dv0[4 * gq + 2], dv0[4 * gq + 3])};
-            const u32x2_t v1 = {pack_bf16x2(dv1[4 * gq], dv1[4 * gq + 1]), pack_bf16x2(dv1[4 * gq + 2], dv1[4 * gq + 3])};
-            *(u32x2_t*)(kp + 8 * gq) = k0;
-            *(u32x2_t*)(kp + 32 + 8 * gq) = k1;
-            *(u32x2_t*)(vp + 8 * gq) = v0;
-            *(u32x2_t*)(vp + 32 + 8 * gq) = v1;
-        }
+        ov_bf16* kp = a.dqkv + ((int64_t)b * L + key) * a.lddq + HD + h * hd;
+        St::store(kp, dk, a.scale, h2, hd);
+        St::store(kp + HD, dv, 1.0f, h2, hd);
     }
 }
 #undef OV_CHUNK_HELPERS
 
 }  // namespace
 
-extern "C" size_t ov_attention_backward_workspace_bytes(int B, int L, int H) {
-    if (B <= 0 || L <= 0 || H <= 0 || L <= 288) return 0;       // the resident kernel needs none
+extern "C" size_t ov_attention_backward_workspace_bytes(int B, int L, int H, int hd) {
+    if (B <= 0 || L <= 0 || H <= 0 || (hd == 64 && L <= 288)) return 0;       // the resident kernel needs none
     const int64_t lpad = (int64_t)(L + CH - 1) / CH * CH;
     return (size_t)2 * B * H * lpad * sizeof(float);
 }
+
+namespace {
+template <int NDH>
+int launch_stream(const AttnBwdSArgs& g, int B, hipStream_t st) {
+    static bool attr = false;
+    const size_t smem = (size_t)2 * Stream<NDH>::IMG + (size_t)2 * CH * sizeof(float);
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_stream_q<NDH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_stream_kv<NDH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return ov_hip(e);
+        attr = true;
+    }
+    const dim3 grid((unsigned)(B * g.a.H * g.nblk));
+    hipLaunchKernelGGL(attn_bwd_stream_q<NDH>, grid, dim3(512), smem, st, g);
+    OV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(attn_bwd_stream_kv<NDH>, grid, dim3(512), smem, st, g);
+    OV_LAUNCH_CHECK();
+    return OV_OK;
+}
+}  // namespace
 
 extern "C" int ov_attention_backward(const ov_bf16* qkv, int64_t ld_qkv, const ov_bf16* out, int64_t ld_out, const ov_bf16* dout,
                                      int64_t ld_dout, ov_bf16* dqkv, int64_t ld_dqkv, int B, int L, int H, int hd, float scale,
                                      void* workspace, size_t workspace_bytes, ov_stream_t stream) {
     if (!qkv || !out || !dout || !dqkv || B <= 0 || L <= 0 || H <= 0) return OV_ERR_INVALID;
-    if (hd != 64) return OV_ERR_UNSUPPORTED;
-    if (ld_qkv % 8 || ld_out % 8 || ld_dout % 8 || ld_dqkv % 8 || ld_qkv < 3 * H * 64 || ld_dqkv < 3 * H * 64 || ld_out < H * 64 ||
-        ld_dout < H * 64)
+    if (hd <= 0 || hd % 8 || hd > 96) return OV_ERR_UNSUPPORTED;
+    if (ld_qkv % 8 || ld_out % 8 || ld_dout % 8 || ld_dqkv % 8 || ld_qkv < 3 * H * hd || ld_dqkv < 3 * H * hd || ld_out < H * hd ||
+        ld_dout < H * hd)
         return OV_ERR_UNSUPPORTED;
     if (((uintptr_t)qkv | (uintptr_t)out | (uintptr_t)dout | (uintptr_t)dqkv) & 15) return OV_ERR_INVALID;
     if ((int64_t)B * H > 0x7fffffffLL) return OV_ERR_UNSUPPORTED;
@@ -534,34 +565,27 @@ extern "C" int ov_attention_backward(const ov_bf16* qkv, int64_t ld_qkv, const o
     a.qkv = qkv; a.ldq = ld_qkv; a.out = out; a.ldo = ld_out; a.dout = dout; a.lddo = ld_dout; a.dqkv = dqkv; a.lddq = ld_dqkv;
     a.L = L; a.H = H; a.KC = (L + 31) / 32 * 32;
     a.scale = scale; a.scale_log2 = scale * 1.4426950408889634f;
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_hd64, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_stream_q, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_stream_kv, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        if (e != hipSuccess) return ov_hip(e);
-        attr = true;
-    }
-    if (L <= 288) {                                             // Q, K, V, dO of a head resident in LDS
+    if (hd == 64 && L <= 288) {                                 // Q, K, V, dO of a head resident in LDS
+        static bool attr = false;
+        if (!attr) {
+            hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_hd64, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return ov_hip(e);
+            attr = true;
+        }
         const size_t smem = (size_t)4 * a.KC * 128 + (size_t)2 * a.KC * sizeof(float);
         hipLaunchKernelGGL(attn_bwd_hd64, dim3((unsigned)(B * H)), dim3((unsigned)(a.KC / 32 * 64)), smem, (hipStream_t)stream, a);
         OV_LAUNCH_CHECK();
         return OV_OK;
     }
     if (!workspace || ((uintptr_t)workspace & 15)) return OV_ERR_INVALID;
-    if (workspace_bytes < ov_attention_backward_workspace_bytes(B, L, H)) return OV_ERR_WORKSPACE;
+    if (workspace_bytes < ov_attention_backward_workspace_bytes(B, L, H, hd)) return OV_ERR_WORKSPACE;
     AttnBwdSArgs g;
     g.a = a;
+    g.hd = hd;
     g.nblk = (L + CH - 1) / CH;
     g.Lpad = g.nblk * CH;
     g.lse = (float*)workspace;
     g.dlt = g.lse + (size_t)B * H * g.Lpad;
     if ((int64_t)B * H * g.nblk > 0x7fffffffLL) return OV_ERR_UNSUPPORTED;
-    const size_t smem = (size_t)2 * CH * 128 + (size_t)2 * CH * sizeof(float);
-    const dim3 grid((unsigned)(B * H * g.nblk));
-    hipLaunchKernelGGL(attn_bwd_stream_q, grid, dim3(512), smem, (hipStream_t)stream, g);
-    OV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(attn_bwd_stream_kv, grid, dim3(512), smem, (hipStream_t)stream, g);
-    OV_LAUNCH_CHECK();
-    return OV_OK;
+    return hd <= 64 ? launch_stream<2>(g, B, (hipStream_t)stream) : launch_stream<3>(g, B, (hipStream_t)stream);
 }

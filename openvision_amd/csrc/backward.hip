@@ -20,7 +20,7 @@ extern "C" int ov_attention(const ov_bf16* qkv, int64_t ld_qkv, ov_bf16* out, in
 extern "C" int ov_attention_backward(const ov_bf16* qkv, int64_t ld_qkv, const ov_bf16* out, int64_t ld_out, const ov_bf16* dout,
                                      int64_t ld_dout, ov_bf16* dqkv, int64_t ld_dqkv, int B, int L, int H, int hd, float scale,
                                      void* workspace, size_t workspace_bytes, ov_stream_t stream);
-extern "C" size_t ov_attention_backward_workspace_bytes(int B, int L, int H);
+extern "C" size_t ov_attention_backward_workspace_bytes(int B, int L, int H, int hd);
 extern "C" int ov_gemm_batched(const ov_bf16* A, int64_t lda, int64_t stride_a, const ov_bf16* W, int64_t ldw, int64_t stride_w,
                                ov_bf16* C, int64_t ldc, int64_t stride_c, int64_t M, int N, int K, int batch, ov_stream_t stream);
 
@@ -458,13 +458,14 @@ inline BlockBufs plan_block(const ov_tower_cfg* c, int B, int L, char* base) {
     lb = lb > l2 ? lb : l2; lb = lb > l3 ? lb : l3; lb = lb > l4 ? lb : l4;
     b.lin_bytes = lb; b.lin = take(lb);
     b.ln_bytes = ov_layernorm_backward_workspace_bytes(M, D); b.ln = take(b.ln_bytes);
-    b.att_bytes = ov_attention_backward_workspace_bytes(B, L, c->heads); b.att = take(b.att_bytes + 256);
+    b.att_bytes = ov_attention_backward_workspace_bytes(B, L, c->heads, c->width / c->heads); b.att = take(b.att_bytes + 256);
     b.total = off;
     return b;
 }
 inline bool block_cfg_ok(const ov_tower_cfg* c) {
-    return c && c->width > 0 && c->heads > 0 && c->width % 64 == 0 && c->width == c->heads * 64 && c->mlp == c->mlp_pad && c->mlp % 64 == 0 &&
-           c->width <= 4096;
+    if (!c || c->width <= 0 || c->heads <= 0 || c->width % 64 || c->width % c->heads || c->width > 4096) return false;
+    const int hd = c->width / c->heads;
+    return hd % 8 == 0 && hd <= 96 && c->mlp > 0 && c->mlp <= c->mlp_pad && c->mlp_pad % 64 == 0;
 }
 }  // namespace
 
@@ -478,7 +479,7 @@ extern "C" int ov_block_backward(const ov_tower_cfg* cfg, const ov_block_weights
                                  size_t workspace_bytes, ov_stream_t stream) {
     if (!cfg || !w || !x || !dy || !dx || !g || !workspace || B <= 0 || L <= 0) return OV_ERR_INVALID;
     if (saved && (!saved->qkv || !saved->attn_out || !saved->x1)) return OV_ERR_INVALID;
-    if (!block_cfg_ok(cfg)) return OV_ERR_UNSUPPORTED;                        // head_dim 64, unpadded MLP
+    if (!block_cfg_ok(cfg)) return OV_ERR_UNSUPPORTED;                        // head_dim % 8 == 0 and <= 96, width % 64 == 0
     if (w->qkv_colsum || w->fc_colsum) return OV_ERR_UNSUPPORTED;             // needs the module's own (unfolded) weights
     if (!w->ln1_w || !w->ln1_b || !w->qkv_w || !w->qkv_b || !w->out_w || !w->out_b || !w->ln2_w || !w->ln2_b || !w->fc_w || !w->fc_b ||
         !w->proj_w || !w->proj_b)
@@ -491,7 +492,8 @@ extern "C" int ov_block_backward(const ov_tower_cfg* cfg, const ov_block_weights
     if (workspace_bytes < ov_block_backward_workspace_bytes(cfg, B, L)) return OV_ERR_WORKSPACE;
     if (((uintptr_t)workspace | (uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) return OV_ERR_INVALID;
     BlockBufs b = plan_block(cfg, B, L, (char*)workspace);
-    const float eps = cfg->ln_eps, scale = 0.125f;
+    const int hd = D / H;
+    const float eps = cfg->ln_eps, scale = 1.0f / sqrtf((float)hd);
     int rc;
 #define OV_TRY(call) do { if ((rc = (call)) != OV_OK) return rc; } while (0)
     // ---- the forward's intermediates: kept by ov_tower_forward_saving (qkv, attention output, x1) or recomputed; the two LayerNorm
@@ -501,7 +503,7 @@ extern "C" int ov_block_backward(const ov_tower_cfg* cfg, const ov_block_weights
         b.qkv = const_cast<ov_bf16*>(saved->qkv); b.o = const_cast<ov_bf16*>(saved->attn_out); b.x1 = const_cast<ov_bf16*>(saved->x1);
     } else {
         OV_TRY(ov_gemm(b.n1, D, w->qkv_w, D, w->qkv_b, b.qkv, 3 * D, M, 3 * D, D, OV_EPI_BIAS, nullptr, 0, 0, 0, 0, stream));
-        OV_TRY(ov_attention(b.qkv, 3 * D, b.o, D, B, L, H, 64, scale, stream));
+        OV_TRY(ov_attention(b.qkv, 3 * D, b.o, D, B, L, H, hd, scale, stream));
         OV_TRY(ov_gemm(b.o, D, w->out_w, D, w->out_b, b.x1, D, M, D, D, OV_EPI_BIAS_RESIDUAL, x, D, 0, 0, 0, stream));
     }
     OV_TRY(ov_layernorm(b.x1, OV_BF16, D, w->ln2_w, w->ln2_b, b.n2, OV_BF16, D, M, D, eps, stream));
@@ -514,7 +516,7 @@ extern "C" int ov_block_backward(const ov_tower_cfg* cfg, const ov_block_weights
     OV_TRY(ov_layernorm_backward(b.x1, D, w->ln2_w, b.t1, D, dy, D, b.dx1, D, g->ln2_w, g->ln2_b, M, D, eps, b.ln, b.ln_bytes, stream)); // dx1 = dy + ...
     // ---- attention branch: x1 = x + out_proj(attn(qkv))
     OV_TRY(ov_linear_backward(b.dx1, D, b.o, D, w->out_w, D, M, D, D, b.t1, D, g->out_w, D, g->out_b, b.lin, b.lin_bytes, stream));     // t1 = d attention out
-    OV_TRY(ov_attention_backward(b.qkv, 3 * D, b.o, D, b.t1, D, b.dqkv, 3 * D, B, L, H, 64, scale, b.att, b.att_bytes, stream));
+    OV_TRY(ov_attention_backward(b.qkv, 3 * D, b.o, D, b.t1, D, b.dqkv, 3 * D, B, L, H, hd, scale, b.att, b.att_bytes, stream));
     OV_TRY(ov_linear_backward(b.dqkv, 3 * D, b.n1, D, w->qkv_w, D, M, 3 * D, D, b.t1, D, g->qkv_w, D, g->qkv_b, b.lin, b.lin_bytes, stream));  // t1 = d ln_1 out
     OV_TRY(ov_layernorm_backward(x, D, w->ln1_w, b.t1, D, b.dx1, D, dx, D, g->ln1_w, g->ln1_b, M, D, eps, b.ln, b.ln_bytes, stream));
 #undef OV_TRY

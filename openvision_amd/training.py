@@ -13,8 +13,8 @@ Opt-in: the inference entry points of ``openvision_amd.model`` never build a gra
 
 Activation memory: the tower keeps, per layer and token, the block input, the packed qkv, the attention output and the mid-block
 residual (6 D bf16: 19 GB for L/14 at B=256, sized for the 288 GB of an MI355X); the LayerNorm outputs and the c_fc
-pre-activation are recomputed during the backward.  Limits of this first version: head_dim 64 and mlp width % 64 == 0
-(Ti, S, B, L towers and their text towers; So400m / H with head_dim 72 / 80 are rejected).
+pre-activation are recomputed during the backward.  Every preset is covered: head dims 72 / 80 (So400m, H/14) take the streaming
+attention backward with d zero-padded to 96, an MLP width that is not a multiple of 64 (So400m) is zero-padded.
 """
 from __future__ import annotations
 
@@ -42,6 +42,18 @@ def _device_copy(p: torch.Tensor) -> torch.Tensor:
     return (p.detach().to(torch.bfloat16) if p.dim() == 2 else p.detach().float()).contiguous()
 
 
+def _pad_mlp(ts: List[torch.Tensor], mlp: int, mlp_pad: int) -> List[torch.Tensor]:
+    """Zero-pad c_fc rows / bias and c_proj columns to the kernels' hidden pitch (a multiple of 64; So400m: 4304 -> 4352)."""
+    if mlp_pad == mlp:
+        return ts
+    pad = mlp_pad - mlp
+    ts = list(ts)
+    ts[8] = torch.cat([ts[8], ts[8].new_zeros(pad, ts[8].shape[1])]).contiguous()
+    ts[9] = torch.cat([ts[9], ts[9].new_zeros(pad)]).contiguous()
+    ts[10] = torch.cat([ts[10], ts[10].new_zeros(ts[10].shape[0], pad)], dim=1).contiguous()
+    return ts
+
+
 class _TowerFn(torch.autograd.Function):
     """Transformer.forward (transformer.py:355-366) as one autograd node over all its blocks."""
 
@@ -50,18 +62,18 @@ class _TowerFn(torch.autograd.Function):
         lib = _lib.load()
         blocks = list(transformer.resblocks)
         b0 = blocks[0]
-        d, heads, mlp = b0.attn.embed_dim, b0.attn.num_heads, b0.mlp_dim
-        if d != heads * 64 or mlp % 64 or d % 64:
-            raise _lib.OvhipError("training path: head_dim 64 and mlp width % 64 == 0 are required")
+        d, heads, mlp, mlp_pad = b0.attn.embed_dim, b0.attn.num_heads, b0.mlp_dim, b0.mlp_pad
+        if d % 64 or d % heads or (d // heads) % 8 or d // heads > 96:
+            raise _lib.OvhipError("training path: width % 64 == 0 and head_dim % 8 == 0, <= 96 are required")
         bsz, seq, _ = x.shape
-        cfg = _lib.TowerCfg(d, len(blocks), heads, mlp, mlp, int(b0.gelu_tanh), float(b0.ln_1.eps))
+        cfg = _lib.TowerCfg(d, len(blocks), heads, mlp, mlp_pad, int(b0.gelu_tanh), float(b0.ln_1.eps))
         handle = lib.ov_tower_create(C.byref(cfg))
         if not handle:
             raise _lib.OvhipError("ov_tower_create failed")
         try:
             keep = []
             for i in range(len(blocks)):
-                ts = [_device_copy(p) for p in params[12 * i:12 * i + 12]]
+                ts = _pad_mlp([_device_copy(p) for p in params[12 * i:12 * i + 12]], mlp, mlp_pad)
                 keep.append(ts)
                 bw = _lib.BlockWeights(*[C.c_void_p(t.data_ptr()) for t in ts], None, None)
                 check(lib.ov_tower_set_block(handle, i, C.byref(bw)), "ov_tower_set_block")
@@ -73,7 +85,7 @@ class _TowerFn(torch.autograd.Function):
                   "ov_tower_forward_saving")
         finally:
             lib.ov_tower_destroy(handle)
-        ctx.cfg, ctx.keep, ctx.saved, ctx.shape = cfg, keep, saved, (bsz, seq, d)
+        ctx.cfg, ctx.keep, ctx.saved, ctx.shape, ctx.mlp = cfg, keep, saved, (bsz, seq, d), mlp
         ctx.x_dtype, ctx.p_dtypes = x.dtype, [p.dtype for p in params]
         return xb.to(x.dtype)
 
@@ -96,6 +108,9 @@ class _TowerFn(torch.autograd.Function):
                   "ov_tower_backward")
         finally:
             lib.ov_tower_destroy(handle)
+        mlp = ctx.mlp                                             # drop the (exactly zero) gradients of the MLP padding
+        for gs in grads:
+            gs[8], gs[9], gs[10] = gs[8][:mlp], gs[9][:mlp], gs[10][:, :mlp]
         flat = [g.to(ctx.p_dtypes[12 * i + j]) for i, gs in enumerate(grads) for j, g in enumerate(gs)]
         return (None, dx.view(bsz, seq, d).to(ctx.x_dtype), *flat)
 

@@ -213,7 +213,7 @@ def block_backward(cfg, weights, x, dy, B, L):
 def attention_backward(qkv, out, dout, B, L, H, hd=64):
     lib = _lib.load()
     dqkv = torch.empty_like(qkv)
-    nb = lib.ov_attention_backward_workspace_bytes(B, L, H)
+    nb = lib.ov_attention_backward_workspace_bytes(B, L, H, hd)
     ws = torch.empty(nb + 256, dtype=torch.uint8, device=qkv.device)
     check(lib.ov_attention_backward(ptr(qkv), qkv.stride(0), ptr(out), out.stride(0), ptr(dout), dout.stride(0), ptr(dqkv), dqkv.stride(0),
                                     B, L, H, hd, hd ** -0.5, ptr(ws), nb, stream_ptr()), "ov_attention_backward")

@@ -70,7 +70,8 @@ def test_argument_validation_of_the_widening_entry_points():
     assert lib.ov_tower_saved_bytes(None, 1, 8) == 0
     assert lib.ov_block_backward_workspace_bytes(None, 1, 8) == 0
     assert lib.ov_attention_backward(None, 192, None, 64, None, 64, None, 192, 1, 8, 1, 64, 0.125, None, 0, None) == -1
-    assert lib.ov_attention_backward_workspace_bytes(2, 257, 16) == 0 and lib.ov_attention_backward_workspace_bytes(2, 2305, 6) >= 2 * 2 * 6 * 2305 * 4
+    assert lib.ov_attention_backward_workspace_bytes(2, 257, 16, 64) == 0 and lib.ov_attention_backward_workspace_bytes(2, 2305, 6, 64) >= 2 * 2 * 6 * 2305 * 4
+    assert lib.ov_attention_backward_workspace_bytes(2, 257, 16, 80) > 0
     assert lib.ov_gemm_batched(None, 64, 64, None, 64, 64, None, 64, 64, 64, 64, 64, 2, None) == -1
     assert lib.ov_linear_backward_workspace_bytes(65792, 4096, 1024) >= 2 * 65792 * (4096 + 1024)
     assert lib.ov_layernorm_backward_workspace_bytes(65792, 1024) > 0

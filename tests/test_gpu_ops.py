@@ -340,6 +340,22 @@ def test_attention_backward_vs_oracle(B, L, H):
     assert torch.equal(again, dqkv)                                       # deterministic
 
 
+@pytest.mark.parametrize("B,L,H,hd", [(2, 257, 4, 72), (2, 257, 3, 80), (1, 40, 2, 72), (1, 300, 2, 80), (1, 65, 2, 32)])
+def test_attention_backward_other_head_dims(B, L, H, hd):
+    """Head dims 72 (So400m) and 80 (H/14) go through the streaming kernels with the d axis zero-padded to 96 in LDS."""
+    qkv = bf(rnd(B * L, 3 * H * hd, seed=52))
+    dout = bf(rnd(B * L, H * hd, seed=53))
+    out = H_.attention(qkv.to(DEV), B, L, H, hd)
+    dqkv = H_.attention_backward(qkv.to(DEV), out, dout.to(DEV), B, L, H, hd).float().cpu()
+    q, k, v = [t.view(B, L, H, hd).transpose(1, 2) for t in qkv.float().view(B, L, 3 * H * hd).split(H * hd, dim=-1)]
+    do = dout.float().view(B, L, H, hd).transpose(1, 2)
+    ref = torch.cat([t.transpose(1, 2).reshape(B * L, H * hd) for t in R.attention_backward(q, k, v, do, hd ** -0.5)], dim=-1)
+    for name, sl in (("dq", slice(0, H * hd)), ("dk", slice(H * hd, 2 * H * hd)), ("dv", slice(2 * H * hd, 3 * H * hd))):
+        got, want = dqkv[:, sl], ref[:, sl]
+        tol = 2e-2 * float(want.abs().max()) + 1e-3
+        assert float((got - want).abs().max()) < tol, (name, float((got - want).abs().max()), tol)
+
+
 def test_attention_backward_golden_reference():
     """Through the reference block's attention module (opgrad.npz): d x = dqkv W_in with an identity out-projection."""
     from conftest import golden
@@ -353,7 +369,7 @@ def test_attention_backward_golden_reference():
     assert float((dx - g["mha_dx"]).abs().max()) < 3e-2 * float(g["mha_dx"].abs().max()) + 2e-3
 
 
-def _block_case(D, heads, mlp, B, L, tanh, seed):
+def _block_case(D, heads, mlp, B, L, tanh, seed, mlp_pad=None):
     """Random block: returns (reference-named fp32 state dict of bf16-rounded weights, C-ABI weight dict on the device, x, dy)."""
     names = {"ln1_w": ("ln_1.weight", (D,), 1.0, 0.1), "ln1_b": ("ln_1.bias", (D,), 0.0, 0.1),
              "qkv_w": ("attn.in_proj_weight", (3 * D, D), 0.0, D ** -0.5), "qkv_b": ("attn.in_proj_bias", (3 * D,), 0.0, 0.05),
@@ -370,6 +386,11 @@ def _block_case(D, heads, mlp, B, L, tanh, seed):
         else:
             dev[k] = t.to(DEV)
         sd["b." + ref] = t.float()
+    if mlp_pad and mlp_pad > mlp:                 # device copies zero-padded to the kernels' hidden pitch (as the forward packs them)
+        pad = mlp_pad - mlp
+        dev["fc_w"] = torch.cat([dev["fc_w"], torch.zeros(pad, D, dtype=torch.bfloat16, device=DEV)]).contiguous()
+        dev["fc_b"] = torch.cat([dev["fc_b"], torch.zeros(pad, device=DEV)]).contiguous()
+        dev["proj_w"] = torch.cat([dev["proj_w"], torch.zeros(D, pad, dtype=torch.bfloat16, device=DEV)], dim=1).contiguous()
     x, dy = bf(rnd(B, L, D, seed=seed + 20)), bf(rnd(B, L, D, seed=seed + 21))
     return names, sd, dev, x, dy
 
@@ -395,6 +416,29 @@ def test_block_backward_vs_oracle(D, heads, mlp, B, L, tanh):
         else:
             e = float((got - want).abs().max())
             assert e < 4e-2 * float(want.abs().max()) + 1e-3, (k, e, float(want.abs().max()))
+
+
+def test_block_backward_head_dim_72_and_padded_mlp():
+    """So400m-like block: head_dim 72 and an MLP width (int(D * 3.7362)) that the kernels pad to a multiple of 64."""
+    from openvision_amd import _lib as L_
+    D, heads, mlp, B, L = 576, 8, 2152, 2, 257
+    mlp_pad = 2176
+    names, sd, dev, x, dy = _block_case(D, heads, mlp, B, L, False, 70, mlp_pad=mlp_pad)
+    cfg = L_.TowerCfg(D, 1, heads, mlp, mlp_pad, 0, 1e-6)
+    dx, grads = H_.block_backward(cfg, dev, x.reshape(B * L, D).to(DEV), dy.reshape(B * L, D).to(DEV), B, L)
+    rdx, rg = R.resblock_backward(x, dy, sd, "b.", heads, False, 1e-6)
+    assert float((dx.float().cpu().view(B, L, D) - rdx).abs().max()) < 4e-2 * float(rdx.abs().max())
+    for k, (ref, shape, _, _) in names.items():
+        got, want = grads[k].float().cpu(), rg[ref]
+        if k in ("fc_w", "fc_b"):
+            assert float(got[mlp:].abs().max()) == 0.0            # the padding rows receive exactly zero
+            got = got[:mlp]
+        if k == "proj_w":
+            got = got[:, :mlp]
+        if len(shape) == 2:
+            assert float((got - want).norm() / want.norm()) < 2e-2, k
+        else:
+            assert float((got - want).abs().max()) < 4e-2 * float(want.abs().max()) + 1e-3, k
 
 
 def test_block_backward_golden_reference():
