@@ -454,23 +454,26 @@ extern "C" int ov_tower_forward_saving(const ov_tower* t, ov_bf16* x, ov_bf16* s
     const int gelu = c.gelu_tanh ? OV_EPI_BIAS_GELU_TANH : OV_EPI_BIAS_GELU_ERF;
     for (int i = 0; i < c.layers; ++i)
         if (!t->set[i] || t->blocks[i].qkv_colsum || t->blocks[i].fc_colsum) return OV_ERR_INVALID;   // the module's own weights
+    // layer i reads its input from its own saved slot and writes its output straight into layer i+1's slot (the last one into x):
+    // one copy for the whole tower
+    hipError_t e = hipMemcpyAsync(saved, x, (size_t)M * D * 2, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    if (e != hipSuccess) return OV_ERR_HIP - (int)e;
     for (int i = 0; i < c.layers; ++i) {
         const ov_block_weights& w = t->blocks[i];
         ov_bf16* sx = saved + (size_t)i * M * 6 * D;
         ov_bf16* sqkv = sx + (size_t)M * D;
         ov_bf16* so = sqkv + (size_t)M * 3 * D;
         ov_bf16* sx1 = so + (size_t)M * D;
-        hipError_t e = hipMemcpyAsync(sx, x, (size_t)M * D * 2, hipMemcpyDeviceToDevice, (hipStream_t)stream);
-        if (e != hipSuccess) return OV_ERR_HIP - (int)e;
+        ov_bf16* y = i + 1 < c.layers ? saved + (size_t)(i + 1) * M * 6 * D : x;
         int rc;
         // the same operator sequence as run_block, with qkv / attention output / x1 written where the backward will read them
-        if ((rc = ov_layernorm(x, OV_BF16, D, w.ln1_w, w.ln1_b, h, OV_BF16, D, M, D, c.ln_eps, stream))) return rc;
+        if ((rc = ov_layernorm(sx, OV_BF16, D, w.ln1_w, w.ln1_b, h, OV_BF16, D, M, D, c.ln_eps, stream))) return rc;
         if ((rc = ov_gemm(h, D, w.qkv_w, D, w.qkv_b, sqkv, 3 * D, M, 3 * D, D, OV_EPI_BIAS, nullptr, 0, 0, 0, 0, stream))) return rc;
         if ((rc = ov_attention(sqkv, 3 * D, so, D, B, L, H, hd, scale, stream))) return rc;
-        if ((rc = ov_gemm(so, D, w.out_w, D, w.out_b, sx1, D, M, D, D, OV_EPI_BIAS_RESIDUAL, x, D, 0, 0, 0, stream))) return rc;
+        if ((rc = ov_gemm(so, D, w.out_w, D, w.out_b, sx1, D, M, D, D, OV_EPI_BIAS_RESIDUAL, sx, D, 0, 0, 0, stream))) return rc;
         if ((rc = ov_layernorm(sx1, OV_BF16, D, w.ln2_w, w.ln2_b, h, OV_BF16, D, M, D, c.ln_eps, stream))) return rc;
         if ((rc = ov_gemm(h, D, w.fc_w, D, w.fc_b, big, ldb, M, c.mlp_pad, D, gelu, nullptr, 0, 0, 0, 0, stream))) return rc;
-        if ((rc = ov_gemm(big, ldb, w.proj_w, c.mlp_pad, w.proj_b, x, D, M, D, c.mlp_pad, OV_EPI_BIAS_RESIDUAL, sx1, D, 0, 0, 0, stream)))
+        if ((rc = ov_gemm(big, ldb, w.proj_w, c.mlp_pad, w.proj_b, y, D, M, D, c.mlp_pad, OV_EPI_BIAS_RESIDUAL, sx1, D, 0, 0, 0, stream)))
             return rc;
     }
     return OV_OK;
