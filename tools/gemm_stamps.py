@@ -1,4 +1,5 @@
-"""Diagnostic: per-tile timeline of the persistent GEMM (s_memtime stamps; 100 MHz constant clock on gfx950)."""
+"""Diagnostic: per-tile timeline of the persistent GEMM from s_memtime stamps.  A tick is one SHADER cycle (MI355X_MICROARCH.md), so
+the numbers below are in units of 100 cycles, and ticks / wall time of the stamped launch gives the clock the kernel actually ran at."""
 import os, sys, torch, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -36,10 +37,14 @@ for name, (N, K, epi) in cases.items():
     ntile = int((st[:, :, 0] > 0).sum(1).max())
     st = st[:, :ntile]
     t0 = st[:, 0, 0].min()
-    us = lambda v: v / 100.0          # s_memtime ticks: 100 MHz
+    us = lambda v: v / 100.0          # s_memtime ticks are shader cycles: unit = 100 cycles
     main = us(st[:, :, 1] - st[:, :, 0]); align = us(st[:, :, 2] - st[:, :, 1]); epi_t = us(st[:, :, 3] - st[:, :, 2])
     gap = us(st[:, 1:, 0] - st[:, :-1, 3]) if ntile > 1 else np.zeros((256, 1))
-    print(f"{name}: kernel {e0.elapsed_time(e1)*1e3:.1f} us, tiles/CU {ntile}, K-tiles {K//64}: main {main.mean():.2f} us "
+    ok = st[:, 0, 0] > 0                                           # the XCDs' counters are not synchronised: span per workgroup
+    span = float(np.median(st[ok][:, :, 3].max(axis=1) - st[ok][:, 0, 0]))   # cycles from its first tile start to its last epilogue end
+    print(f"{name}: shader clock during the launch ~ {span / (e0.elapsed_time(e1) * 1e-3) / 1e9:.2f} GHz ({span:.0f} cycles in {e0.elapsed_time(e1)*1e3:.1f} us; "
+          f"K-tile floor = 2048 MFMA cycles per SIMD)")
+    print(f"{name}: kernel {e0.elapsed_time(e1)*1e3:.1f} us, tiles/CU {ntile}, K-tiles {K//64} [unit: 100 cycles]: main {main.mean():.2f} "
           f"(min {main.min():.2f} max {main.max():.2f}) = {main.mean()/(K//64):.3f} us/K-tile; align {align.mean():.2f}; "
           f"epilogue {epi_t.mean():.2f} (min {epi_t.min():.2f} max {epi_t.max():.2f}); restart gap {gap.mean():.2f}; "
           f"first start spread {us(st[:,0,0].max()-t0):.2f}, last end spread {us(st[:,-1,3].max()-st[:,-1,3].min()):.2f}")
