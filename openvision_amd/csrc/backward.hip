@@ -27,8 +27,11 @@ extern "C" int ov_gemm_batched(const ov_bf16* A, int64_t lda, int64_t stride_a, 
 namespace {
 
 // out[c, r] = in[r, c] for r < R, 0 for R <= r < Rpad (Rpad = R rounded up to 64: the GEMM's K granule).  64 x 64 tiles.
+// SUMS: also writes the fp32 column sums of each 64-row tile to colpart[row tile][C] (the bias gradient rides on the pass that
+// transposes dY for the weight gradient).
+template <bool SUMS>
 __global__ __launch_bounds__(256) void transpose_bf16(const unsigned short* __restrict__ in, int64_t ld_in, int64_t R, int C,
-                                                      unsigned short* __restrict__ out, int64_t ld_out) {
+                                                      unsigned short* __restrict__ out, int64_t ld_out, float* __restrict__ colpart) {
     __shared__ unsigned short tile[64][66];                       // tile[c][r], 33-dword rows: conflict-free both ways
     const int64_t r0 = (int64_t)blockIdx.x * 64;
     const int c0 = blockIdx.y * 64;
@@ -45,6 +48,17 @@ __global__ __launch_bounds__(256) void transpose_bf16(const unsigned short* __re
         }
     }
     __syncthreads();
+    if (SUMS) {       // thread (c, quarter) sums 16 rows of column c as eight packed pairs; the quarters meet in LDS
+        __shared__ float red[4][64];
+        const int c = t & 63, qd = t >> 6;
+        const unsigned int* rp = (const unsigned int*)&tile[c][qd * 16];       // 132-byte rows: 4-byte aligned
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const unsigned int w = rp[i]; acc += bf16lo_to_f32(w); acc += bf16hi_to_f32(w); }
+        red[qd][c] = acc;
+        __syncthreads();
+        if (t < 64 && c0 + t < C) colpart[(int64_t)blockIdx.x * C + c0 + t] = ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t];
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int c = (t >> 3) + 32 * h, r8 = (t & 7) * 8;
@@ -306,9 +320,14 @@ inline SplitK plan_splitk(int64_t M, int N, int K) {
 }
 
 // Rpad: multiple of 64 >= R; tiles past R are written as zeros
-int launch_transpose(const ov_bf16* in, int64_t ld_in, int64_t R, int64_t Rpad, int C, ov_bf16* out, int64_t ld_out, hipStream_t st) {
+int launch_transpose(const ov_bf16* in, int64_t ld_in, int64_t R, int64_t Rpad, int C, ov_bf16* out, int64_t ld_out, hipStream_t st,
+                     float* colpart = nullptr) {
     const dim3 grid((unsigned)(Rpad / 64), (unsigned)((C + 63) / 64));
-    hipLaunchKernelGGL(transpose_bf16, grid, dim3(256), 0, st, (const unsigned short*)in, ld_in, R, C, (unsigned short*)out, ld_out);
+    if (colpart)
+        hipLaunchKernelGGL(transpose_bf16<true>, grid, dim3(256), 0, st, (const unsigned short*)in, ld_in, R, C, (unsigned short*)out, ld_out, colpart);
+    else
+        hipLaunchKernelGGL(transpose_bf16<false>, grid, dim3(256), 0, st, (const unsigned short*)in, ld_in, R, C, (unsigned short*)out, ld_out,
+                           (float*)nullptr);
     OV_LAUNCH_CHECK();
     return OV_OK;
 }
@@ -328,7 +347,7 @@ extern "C" size_t ov_linear_backward_workspace_bytes(int64_t M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     const SplitK sp = plan_splitk(M, N, K);
     return align256((size_t)K * N * 2) + align256((size_t)N * sp.mp * 2) + align256((size_t)K * sp.mp * 2) +
-           align256((size_t)sp.nz * N * K * 2) + align256((size_t)((M + CS_ROWS - 1) / CS_ROWS) * N * 4) +
+           align256((size_t)sp.nz * N * K * 2) + align256((size_t)(sp.mp / 64) * N * 4) +     // >= the M / 256 chunk partials
            align256((size_t)RS_SPLIT * N * 4);
 }
 
@@ -358,7 +377,7 @@ extern "C" int ov_linear_backward(const ov_bf16* dY, int64_t lddy, const ov_bf16
     }
     if (dW) {       // dW[N, K] = dY^T[N, M] . X[M, K]  =  ov_gemm(A = dY^T [N, Mpad], "W" = X^T [K, Mpad]) contracting over Mpad (zeros past M)
         if (sp.chunk > 0x7fffffffLL) return OV_ERR_UNSUPPORTED;
-        if ((rc = launch_transpose(dY, lddy, M, mp, N, dYt, mp, st)) != OV_OK) return rc;
+        if ((rc = launch_transpose(dY, lddy, M, mp, N, dYt, mp, st, db ? part : nullptr)) != OV_OK) return rc;   // + per-tile column sums
         if ((rc = launch_transpose(X, ldx, M, mp, K, Xt, mp, st)) != OV_OK) return rc;
         if (sp.nz == 1) {
             if ((rc = ov_gemm(dYt, mp, Xt, mp, nullptr, dW, lddw, N, K, (int)mp, OV_EPI_BIAS, nullptr, 0, 0, 0, 0, stream)) != OV_OK) return rc;
@@ -373,13 +392,17 @@ extern "C" int ov_linear_backward(const ov_bf16* dY, int64_t lddy, const ov_bf16
             OV_LAUNCH_CHECK();
         }
     }
-    if (db) {
+    if (db && dW) {  // the column sums of dY came with its transpose: one partial row per 64-row tile
+        const int64_t ntile = mp / 64;
+        float* scratch = (float*)((char*)part + align256((size_t)ntile * N * 4));
+        if ((rc = launch_rows_sum(part, ntile, N, (int64_t)N, scratch, db, st)) != OV_OK) return rc;
+    } else if (db) {
         const int64_t nchunk = (M + CS_ROWS - 1) / CS_ROWS;
         if (nchunk > 65535) return OV_ERR_UNSUPPORTED;
         hipLaunchKernelGGL(colsum_partial, dim3((unsigned)((N / 2 + 255) / 256), (unsigned)nchunk), dim3(256), 0, st,
                            (const unsigned int*)dY, lddy / 2, M, N / 2, part);
         OV_LAUNCH_CHECK();
-        float* scratch = (float*)((char*)part + align256((size_t)nchunk * N * 4));
+        float* scratch = (float*)((char*)part + align256((size_t)(mp / 64) * N * 4));
         if ((rc = launch_rows_sum(part, nchunk, N, (int64_t)N, scratch, db, st)) != OV_OK) return rc;
     }
     return OV_OK;
