@@ -1,11 +1,13 @@
 """Counterpart of the fork's ``ov-zero-shot-test.py`` on the MI355X path.
 
+    python -m openvision_amd.zero_shot --use_model DIR --image_dir testcat --prompts "a cat|a dog|a remote control"
     python -m openvision_amd.zero_shot --use_model DIR --image_dir testcat --tokens prompts.npy [--labels a,b,c]
 
 Reproduces the script's observable behaviour: config-dir loading (:37-56), the printed visual-config block (:59-65),
-the per-image sorted cosine / probability table (:167-195) and the per-text best image (:198-208).  Differences, both
-outside the hot path: the HF tokenizer needs the hub (``ov-zero-shot-test.py:81``), so prompts are given as an int64
-``[n, context_length]`` ``.npy`` of token ids; image resize/normalise uses PIL + numpy instead of torchvision.
+the per-image sorted cosine / probability table (:167-195) and the per-text best image (:198-208).  Prompts are tokenised by
+``openvision_amd.tokenizer`` (the reference's WordPiece tokenizer restated; ``<DIR>/vocab.txt`` if present, else the packaged
+vocabulary) or given as an int64 ``[n, context_length]`` ``.npy`` of token ids; image resize/normalise uses PIL + numpy
+instead of torchvision.
 ``DIR`` holds ``open_clip_config.json`` and either ``open_clip_pytorch_model.bin`` (loaded with
 ``torch.load(weights_only=True)``) or, with ``--synthetic``, formula weights.
 """
@@ -60,7 +62,8 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     ap = argparse.ArgumentParser(description="OpenVision Text-Image Test (MI355X)")
     ap.add_argument("--use_model", required=True)
     ap.add_argument("--image_dir", default="testcat")
-    ap.add_argument("--tokens", required=True, help=".npy int64 [n, context_length] token ids")
+    ap.add_argument("--tokens", default="", help=".npy int64 [n, context_length] token ids")
+    ap.add_argument("--prompts", default="", help="'|'-separated prompt texts (tokenised here)")
     ap.add_argument("--labels", default="")
     ap.add_argument("--synthetic", action="store_true", help="formula weights instead of open_clip_pytorch_model.bin")
     a = ap.parse_args(argv)
@@ -73,8 +76,18 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
                          device="cuda:0", state_dict=sd)
     print(describe(model))
     names, imgs = load_images(a.image_dir, model_cfg["vision_cfg"]["image_size"], pp["mean"], pp["std"])
-    tokens = torch.from_numpy(np.load(a.tokens, allow_pickle=False).astype(np.int64))
-    labels = a.labels.split(",") if a.labels else [f"prompt {i}" for i in range(tokens.shape[0])]
+    if bool(a.tokens) == bool(a.prompts):
+        ap.error("give exactly one of --tokens / --prompts")
+    if a.prompts:
+        from .tokenizer import WordPieceTokenizer
+        texts = [t.strip() for t in a.prompts.split("|")]
+        vocab = os.path.join(a.use_model, "vocab.txt")
+        tok = WordPieceTokenizer(vocab if os.path.exists(vocab) else None, context_length=model_cfg["text_cfg"]["context_length"])
+        tokens = tok(texts)
+        labels = a.labels.split(",") if a.labels else texts
+    else:
+        tokens = torch.from_numpy(np.load(a.tokens, allow_pickle=False).astype(np.int64))
+        labels = a.labels.split(",") if a.labels else [f"prompt {i}" for i in range(tokens.shape[0])]
     cos, probs, order = zero_shot_table(model, imgs.to("cuda:0"), tokens.to("cuda:0"))
     cos, probs, order = cos.cpu(), probs.cpu(), order.cpu()
     print("\n=== Cosine Similarities and Predictions ===")

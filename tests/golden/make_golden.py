@@ -21,11 +21,13 @@ Files written (np.savez_compressed):
   cliploss_ws.npz         ClipLoss(local_loss=True) per-rank losses at world_size 2 and 8 over gloo
   opgrad.npz              autograd through the reference's LayerNorm / nn.Linear / nn.GELU for random upstream gradients
   blockgrad.npz           autograd through the reference ResidualAttentionBlock (Tiny block 0): d input + parameter gradients
+  tokenizer.npz           caption token ids [N, 80] from the tokenizers library on the reference's vocabulary, reference framing
   cliploss_grad.npz       autograd gradients of ClipLoss at world_size 1 and per rank at world_size 2
 """
 from __future__ import annotations
 
 import argparse
+import html
 import importlib
 import os
 import sys
@@ -396,6 +398,41 @@ def gen_blockgrad(tr, out):
     np.savez_compressed(out, **res)
 
 
+def gen_tokenizer(ref_root, out):
+    """Token ids of the reference's caption tokenizer: HuggingFace `tokenizers` BertWordPieceTokenizer (the third-party library
+    CustomTokenizer wraps, tokenizer.py:522-550) on the reference's vocabulary asset, framed as CustomTokenizer.tokenize /
+    pad_and_add_class_token do (bos 1, at most 77 pieces, eos 2, zero padding, class token 101 last).  The vendored tokenizer
+    module itself cannot be imported (ftfy missing), so its five framing lines are restated here; captions are chosen so that
+    ftfy.fix_text would leave them unchanged."""
+    import random
+    from tokenizers import BertWordPieceTokenizer
+    vocab = os.path.join(ref_root, "assets", "bert_base_vocab_bos_eos.txt")
+    tk = BertWordPieceTokenizer.from_file(vocab)
+    words = [l.rstrip("\n") for l in open(vocab, encoding="utf-8")]
+    texts = ["a photo of a cat", "a photo of a dog", "A Photo Of A CAT.", "a cat sitting on a sofa, looking at the camera",
+             "an image of two cats and a remote control", "the quick brown fox jumps over the lazy dog", "", "   ",
+             "Hello, world! It's 5:30pm -- really?", "don't can't won't i'm", "naive cafe resume", "na\u00efve caf\u00e9 r\u00e9sum\u00e9",
+             "\u00dcber stra\u00dfe \u00e5ngstr\u00f6m", "price: $5.00 + 10% tax = $5.50", "x_y-z/w\\v a|b c^d e~f", "e-mail: someone@example.com",
+             "\u65e5\u672c\u8a9e\u306e\u30c6\u30ad\u30b9\u30c8", "a photo of a \u732b and a \u72ac", "\ud55c\uad6d\uc5b4 \ud14d\uc2a4\ud2b8", "\u0440\u0443\u0441\u0441\u043a\u0438\u0439 \u0442\u0435\u043a\u0441\u0442",
+             "\u0395\u03bb\u03bb\u03b7\u03bd\u03b9\u03ba\u03ac \u039f\u0394\u039f\u03a3", "emoji \U0001f600 test", "tab\tseparated\nlines\r\nend", "multiple     spaces   here",
+             "supercalifragilisticexpialidocious", "a" * 120, "pneumonoultramicroscopicsilicovolcanoconiosis " * 3,
+             "word " * 100, "unaffable unbelievably antidisestablishmentarianism", "[UNK] [SEP] [CLS] [MASK] [PAD] literal specials",
+             "&amp; &lt;tag&gt; &amp;amp; html entities", "1234567890 3.14159 1,000,000", "UPPER lower MiXeD CaSe", "(parentheses) [brackets] {braces}"]
+    rnd = random.Random(2024)
+    for _ in range(160):                                    # vocabulary words in random order: long and short captions
+        n = rnd.randint(1, 60)
+        texts.append(" ".join(rnd.choice(words).replace("##", "") for _ in range(n)))
+    clean_ = lambda t: " ".join(html.unescape(html.unescape(t)).strip().split()).strip()     # _clean_whitespace minus ftfy
+    rows = []
+    for t in texts:
+        ids = tk.encode(clean_(t), add_special_tokens=False).ids[:80 - 3]
+        enc = [1] + ids + [2]
+        if len(enc) < 80 - 1:
+            enc += [0] * (80 - 1 - len(enc))
+        rows.append(enc + [101])
+    np.savez_compressed(out, texts=np.array(texts), ids=np.array(rows, dtype=np.int64))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -414,6 +451,7 @@ def main():
         "preprocess": lambda: gen_preprocess(a.ref, os.path.join(HERE, "preprocess.npz")),
         "opgrad": lambda: gen_opgrad(tr, os.path.join(HERE, "opgrad.npz")),
         "blockgrad": lambda: gen_blockgrad(tr, os.path.join(HERE, "blockgrad.npz")),
+        "tokenizer": lambda: gen_tokenizer(a.ref, os.path.join(HERE, "tokenizer.npz")),
         "lossgrad": lambda: gen_lossgrad(lossmod, a.ref, os.path.join(HERE, "cliploss_grad.npz")),
     }
     for k, fn in jobs.items():

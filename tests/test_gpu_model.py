@@ -452,3 +452,16 @@ def test_data_parallel_training_matches_single_process():
         assert abs(float(d_.norm()) - float(g.norm())) < 0.03 * float(g.norm()), name
         checked += 1
     assert checked > 100
+
+
+def test_tokenizer_feeds_encode_text(tiny):
+    """Captions -> openvision_amd.tokenizer -> encode_text: ids in range, embeddings equal to the oracle's on the same ids."""
+    from oracle import clip_ref as R
+    from openvision_amd.tokenizer import WordPieceTokenizer
+    cfg = preset("vit-tiny-patch16-160")
+    tok = WordPieceTokenizer(context_length=cfg["text_cfg"]["context_length"])
+    ids = tok(["a photo of a cat", "a photo of a dog", "two cats sleeping on a pink couch next to remote controls", ""])
+    assert int(ids.max()) < cfg["text_cfg"]["vocab_size"] and ids.shape == (4, 80)
+    f = tiny.encode_text(ids.to(DEV), normalize=True).cpu()
+    ref = R.encode_text(ids, synth.make_state_dict(cfg), cfg, True)
+    assert one_minus_cos(f, ref) < 1e-3
