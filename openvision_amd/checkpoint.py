@@ -4,7 +4,8 @@ What the reference does: read ``open_clip_config.json``, build ``CLIP(vision_cfg
 ``open_clip_pytorch_model.bin`` and ``load_state_dict`` strictly (``ov-zero-shot-test.py:37-56``); the converter defines the
 file names (``src/convert_upload/transfer_jax2hf.py:71-72,637``: ``open_clip_pytorch_model.bin``, and the never-written
 ``open_clip_model.safetensors``).  Here both are accepted; ``.bin`` is read with ``weights_only=True`` (no code execution).
-The orbax/JAX side of the converter needs jax and is out of scope.
+Reading an orbax checkpoint needs jax/orbax and is out of scope; the converter's JAX -> open_clip key map on a flat
+name -> array dictionary is in ``openvision_amd.convert_jax``.
 """
 from __future__ import annotations
 
