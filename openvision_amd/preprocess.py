@@ -7,7 +7,7 @@ Reference: ``transforms.Resize((S, S)) -> convert("RGB") -> ToTensor -> Normaliz
 fixed-point convolution.  ``resize_plan`` below restates its ``precompute_coeffs`` / ``normalize_coeffs_8bpc`` in the same double
 arithmetic, the kernels (``csrc/preprocess.hip``) do the integer convolution, so the uint8 image equals Pillow's bit for bit.
 
-The tokenizer half of that row is not provided: the HF tokenizer vocabulary is not available offline.
+The tokenizer half of that row is ``openvision_amd.tokenizer``.
 """
 from __future__ import annotations
 
