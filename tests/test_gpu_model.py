@@ -465,3 +465,19 @@ def test_tokenizer_feeds_encode_text(tiny):
     f = tiny.encode_text(ids.to(DEV), normalize=True).cpu()
     ref = R.encode_text(ids, synth.make_state_dict(cfg), cfg, True)
     assert one_minus_cos(f, ref) < 1e-3
+
+
+def test_zero_shot_cli_with_text_prompts(tiny, tmp_path, capsys):
+    """python -m openvision_amd.zero_shot with --prompts: config directory, images from disk, prompts tokenised here."""
+    from PIL import Image
+    from openvision_amd import checkpoint, zero_shot
+    cfg = preset("vit-tiny-patch16-160")
+    mdir, idir = tmp_path / "model", tmp_path / "images"
+    checkpoint.save_pretrained(tiny, cfg, str(mdir))
+    idir.mkdir()
+    rng = np.random.default_rng(3)
+    for i in range(3):
+        Image.fromarray(rng.integers(0, 256, size=(90 + 10 * i, 120, 3), dtype=np.uint8)).save(idir / f"img{i}.png")
+    rc = zero_shot.main(["--use_model", str(mdir), "--image_dir", str(idir), "--prompts", "a photo of a cat|a photo of a dog|a remote control"])
+    out = capsys.readouterr().out
+    assert rc == 0 and "Best Image Per Text" in out and "a photo of a dog" in out and out.count("cosine:") == 9
