@@ -6,8 +6,8 @@
 Reproduces the script's observable behaviour: config-dir loading (:37-56), the printed visual-config block (:59-65),
 the per-image sorted cosine / probability table (:167-195) and the per-text best image (:198-208).  Prompts are tokenised by
 ``openvision_amd.tokenizer`` (the reference's WordPiece tokenizer restated; ``<DIR>/vocab.txt`` if present, else the packaged
-vocabulary) or given as an int64 ``[n, context_length]`` ``.npy`` of token ids; image resize/normalise uses PIL + numpy
-instead of torchvision.
+vocabulary) or given as an int64 ``[n, context_length]`` ``.npy`` of token ids; images are decoded on the host and resized /
+normalised on the device (``openvision_amd.preprocess``).
 ``DIR`` holds ``open_clip_config.json`` and either ``open_clip_pytorch_model.bin`` (loaded with
 ``torch.load(weights_only=True)``) or, with ``--synthetic``, formula weights.
 """
@@ -26,14 +26,14 @@ from .model import create_model, logits
 
 
 def load_images(image_dir: str, size: int, mean: Sequence[float], std: Sequence[float]) -> Tuple[List[str], torch.Tensor]:
+    """Decode on the host, then Resize((S, S)) -> ToTensor -> Normalize (ov-zero-shot-test.py:72-77) on the device with
+    ``openvision_amd.preprocess`` (bit-exact against Pillow for RGB files; other modes are converted to RGB before the resize,
+    where the script resizes in the file's own mode first)."""
     from PIL import Image
+    from .preprocess import preprocess
     names = [n for n in sorted(os.listdir(image_dir)) if n.lower().endswith((".png", ".jpg", ".jpeg", ".webp"))]
-    out = []
-    for n in names:
-        im = Image.open(os.path.join(image_dir, n)).convert("RGB").resize((size, size), Image.BILINEAR)
-        a = (np.asarray(im, dtype=np.float32) / 255.0 - np.asarray(mean, np.float32)) / np.asarray(std, np.float32)
-        out.append(a.transpose(2, 0, 1))
-    return names, torch.from_numpy(np.stack(out))
+    raw = [np.asarray(Image.open(os.path.join(image_dir, n)).convert("RGB"), dtype=np.uint8) for n in names]
+    return names, preprocess(raw, size, mean=mean, std=std, resize_mode="squash", interpolation="bilinear")
 
 
 def describe(model) -> str:
