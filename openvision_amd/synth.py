@@ -62,8 +62,42 @@ def _block(sd: Dict[str, torch.Tensor], prefix: str, d: int, mlp: int, seed: int
     n("mlp.c_proj.bias", (d,), 0.1)
 
 
-def make_state_dict(model_cfg: Dict[str, Any], seed: int = 0) -> Dict[str, torch.Tensor]:
-    """fp32 state dict for ``CLIP(**model_cfg)`` (reference key names and shapes)."""
+def make_state_dict(model_cfg: Dict[str, Any], seed: int = 0, variant: str = "v1") -> Dict[str, torch.Tensor]:
+    """fp32 state dict for ``CLIP(**model_cfg)`` (reference key names and shapes).
+
+    ``variant="v1"``: plain random weights — the encoder they define is nearly input-independent (different images land
+    within cos 0.99 of each other), good for throughput runs and operator-level parity only.
+    ``variant="sharp"``: the same draws reshaped so that distinct inputs give separated embeddings (peaked attention,
+    small biases, mean-free MLP output projections, a decaying spectrum shared by both output projections): the weight
+    set of the discriminating parity fixtures (``tests/golden/*_sharp.npz``)."""
+    sd = _make_v1(model_cfg, seed)
+    if variant == "sharp":
+        _sharpen(sd, int(model_cfg["embed_dim"]))
+    elif variant != "v1":
+        raise ValueError(f"unknown weight variant {variant!r}")
+    return sd
+
+
+SHARP = {"qk_vision": 2.5, "qk_text": 1.5, "bias": 0.2, "token_embedding": 2.0, "spectrum": 4.0}
+
+
+def _sharpen(sd: Dict[str, torch.Tensor], e: int) -> None:
+    prof = 1.0 / (1.0 + torch.arange(e, dtype=torch.float32) / SHARP["spectrum"])
+    prof = prof / prof.norm() * math.sqrt(e)
+    for k in list(sd):
+        if k.endswith(".bias") or k.endswith("in_proj_bias"):
+            sd[k] = sd[k] * SHARP["bias"]
+        elif k.endswith("c_proj.weight"):
+            sd[k] = sd[k] - sd[k].mean(dim=1, keepdim=True)
+        elif k.endswith("in_proj_weight"):
+            d = sd[k].shape[1]
+            sd[k][:2 * d] *= SHARP["qk_vision"] if k.startswith("visual.") else SHARP["qk_text"]
+    sd["token_embedding.weight"] = sd["token_embedding.weight"] * SHARP["token_embedding"]
+    sd["visual.proj"] = sd["visual.proj"] * prof
+    sd["text_projection"] = sd["text_projection"] * prof
+
+
+def _make_v1(model_cfg: Dict[str, Any], seed: int = 0) -> Dict[str, torch.Tensor]:
     v = vision_cfg_from(model_cfg["vision_cfg"])
     t = text_cfg_from(model_cfg["text_cfg"])
     e = int(model_cfg["embed_dim"])
@@ -95,6 +129,16 @@ def make_state_dict(model_cfg: Dict[str, Any], seed: int = 0) -> Dict[str, torch
 def make_images(batch: int, image_size: int, seed: int = 0) -> torch.Tensor:
     """[B,3,S,S] ~ N(0,1): the distribution after Normalize (ov-zero-shot-test.py:76)."""
     return _normal("synthetic.images", (batch, 3, image_size, image_size), 1.0, seed)
+
+
+def make_structured_images(batch: int, image_size: int, seed: int = 0) -> torch.Tensor:
+    """[B,3,S,S]: 0.6 * N(0,1) pixel noise + a smooth per-image colour field (a 4x4x3 N(0,1) grid, bilinearly upsampled).
+    Unlike ``make_images`` the images differ in their global statistics, which is what survives the tower's mean pooling:
+    the inputs of the discriminating fixtures (committed there as fp16, so the interpolation need not be bit-stable)."""
+    noise = _normal("synthetic.structured.noise", (batch, 3, image_size, image_size), 0.6, seed)
+    low = _normal("synthetic.structured.field", (batch, 3, 4, 4), 1.0, seed)
+    low = torch.nn.functional.interpolate(low, size=(image_size, image_size), mode="bilinear", align_corners=False)
+    return noise + low
 
 
 def make_captions(batch: int, context_length: int = 80, vocab_size: int = 32000, seed: int = 0,

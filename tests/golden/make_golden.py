@@ -15,7 +15,8 @@ Files written (np.savez_compressed):
   ops.npz                 LayerNorm / GELU(erf,tanh) / ResidualAttentionBlock of the reference on small inputs
   tiny16_160.npz          Ti/16@160 + text-Ti: tokens after block 0 / last block, features, logits, loss
   preprocess.npz          Pillow resize / ToTensor / Normalize outputs on the testcat PNGs and three synthetic images
-  tiny16_160_testcat.npz  the 5 testcat PNGs (resized to 160, normalised) x 9 caption rows: cosine/probs/argsort
+  tiny16_160_testcat.npz  the 5 testcat PNGs (resized to 160, normalised) x 9 caption rows: cosine/probs/argsort ('sharp' weights)
+  *_sharp.npz             Ti/16, L/14, S/8 on the 'sharp' weights + structured images: separated embeddings, per-block slices
   large14_224.npz         L/14@224 + text-L, B=2: features (fp32 and the reference's bf16 mode), token slices
   small8_384.npz          S/8@384, B=1 (2305 tokens): features, token slices
   cliploss_ws.npz         ClipLoss(local_loss=True) per-rank losses at world_size 2 and 8 over gloo
@@ -64,10 +65,10 @@ def import_reference(ref_root: str):
             importlib.import_module("open_clip.transformer"))
 
 
-def build_ref(m, model_cfg, seed=0, cast_dtype=None):
+def build_ref(m, model_cfg, seed=0, cast_dtype=None, variant="v1"):
     model = m.CLIP(embed_dim=model_cfg["embed_dim"], vision_cfg=dict(model_cfg["vision_cfg"]),
                    text_cfg=dict(model_cfg["text_cfg"]), cast_dtype=cast_dtype)
-    sd = synth.make_state_dict(model_cfg, seed)
+    sd = synth.make_state_dict(model_cfg, seed, variant)
     model.load_state_dict(sd, strict=True)       # ov-zero-shot-test.py:54
     model.eval()
     if cast_dtype is not None:
@@ -144,28 +145,99 @@ def load_testcat(ref_root, size, mean, std):
     return names, torch.from_numpy(np.stack(arr)).half().float()   # stored as fp16
 
 
+TOPK_GAP = 5e-2      # margin the fixtures are built with: neighbouring ranks of the reference this far apart
+
+
+def leading_ranks(row, gap):
+    """Number of leading positions of the descending order of `row` that are determined at margin `gap`."""
+    srt = np.sort(row)[::-1]
+    k = 0
+    while k + 1 < len(srt) and srt[k] - srt[k + 1] > gap:
+        k += 1
+    return k
+
+
 def gen_testcat(m, ref_root, out):
-    """Counterpart of ov-zero-shot-test.py:157-195 on formula weights.  The HF tokenizer is unavailable
-    offline, so the 9 'prompts' are committed token-id rows in the training format."""
+    """Counterpart of ov-zero-shot-test.py:157-195 on formula weights (the 'sharp' set: distinct inputs give separated
+    embeddings).  The HF tokenizer is unavailable offline, so the 9 'prompts' are committed token-id rows in the training
+    format, selected so that the reference's own cosine table separates neighbouring ranks of every row by more than
+    TOPK_GAP (fixtures are built with margins)."""
     cfg = ovcfg.preset("vit-tiny-patch16-160")
-    model = build_ref(m, cfg)
+    model = build_ref(m, cfg, variant="sharp")
     pp = ovcfg.DEFAULT_PREPROCESS
     names, img = load_testcat(ref_root, 160, pp["mean"], pp["std"])
-    tok = synth.make_captions(9, 80, 32000, seed=7)
     with torch.no_grad():
-        tf = model.encode_text(tok)
-        tf = tf / tf.norm(dim=-1, keepdim=True)
-        cos, probs = [], []
+        feats = []
         for i in range(img.shape[0]):                      # batch = 1 per image, as the script does
             f = model.encode_image(img[i:i + 1])
-            f = f / f.norm(dim=-1, keepdim=True)
-            c = (f @ tf.T)[0]
-            cos.append(c)
-            probs.append((model.logit_scale.exp() * c).softmax(dim=-1))
-        cos, probs = torch.stack(cos), torch.stack(probs)
+            feats.append(f / f.norm(dim=-1, keepdim=True))
+        feats = torch.cat(feats)
+        # 9 caption rows picked greedily from a seeded pool so that, in every image's row, the chosen captions' cosines
+        # are pairwise at least TOPK_GAP apart: the reference's whole ranking is then decided with margin
+        pool = synth.make_captions(4096, 80, 32000, seed=7)
+        pf = model.encode_text(pool)
+        pf = pf / pf.norm(dim=-1, keepdim=True)
+        pc = (feats @ pf.T).numpy()                        # [5, pool]
+        chosen = []
+        for j in np.argsort(pc.mean(axis=0)):              # sweep in order of the mean cosine: 1-D interval packing
+            if all(np.abs(pc[:, j] - pc[:, c]).min() > TOPK_GAP * 1.02 for c in chosen):
+                chosen.append(int(j))
+        if len(chosen) < 9:
+            raise RuntimeError(f"caption pool gives only {len(chosen)} separated rows")
+        chosen = [chosen[i] for i in np.linspace(0, len(chosen) - 1, 9).round().astype(int)]
+        chosen = sorted(chosen)
+        tok, cos = pool[chosen], feats @ pf[chosen].T
+        probs = (model.logit_scale.exp() * cos).softmax(dim=-1)
+    print("  testcat: pool rows", chosen, "leading ranks per row", [leading_ranks(r, TOPK_GAP) for r in cos.numpy()])
     np.savez_compressed(out, names=np.array(names), images=img.numpy().astype(np.float16), tokens=tok.numpy(),
                         cosine=f32(cos), probs=f32(probs), argsort=cos.argsort(dim=-1, descending=True).numpy(),
-                        best=probs.argmax(dim=-1).numpy())
+                        best=probs.argmax(dim=-1).numpy(), pool_rows=np.array(chosen), variant=np.array("sharp"))
+
+
+def gen_sharp(m, lossmod, outdir):
+    """Discriminating fixtures: 'sharp' formula weights + structured images (synth.make_structured_images), so that a wrong
+    row, a wrong image or an input-independent encoder FAILS the 1e-3 cosine gate (on the v1 weights two different images sit
+    at cos 0.992 of each other).  Per-block residual-stream slices are kept for the HIP path's block-level comparison."""
+    def run(pname, size, nimg, blocks, seed, tail, text=True, bf16=False):
+        cfg = ovcfg.preset(pname)
+        model = build_ref(m, cfg, variant="sharp")
+        img = synth.make_structured_images(nimg, size, seed=seed).half().float()      # stored as fp16
+        tok = synth.make_captions(max(nimg, 4), 80, 32000, seed=seed)
+        hs = tokens_after_blocks(model, img, blocks)
+        res = {"images": img.numpy().astype(np.float16), "tokens": tok.numpy(), "variant": np.array("sharp")}
+        with torch.no_grad():
+            fi = model.encode_image(img)
+            res["image_features"] = f32(fi)
+            ni = fi / fi.norm(dim=-1, keepdim=True)
+            res["image_image_cos"] = f32(ni @ ni.T)
+            if text:
+                ft = model.encode_text(tok)
+                nt = ft / ft.norm(dim=-1, keepdim=True)
+                res.update(text_features=f32(ft), text_text_cos=f32(nt @ nt.T), cosine=f32(ni @ nt.T),
+                           argsort=(ni @ nt.T).argsort(dim=-1, descending=True).numpy())
+                if nimg == tok.shape[0]:
+                    a, b, s = model(img, tok)
+                    res["loss"] = f32(lossmod.ClipLoss()(a, b, s))
+        for i in blocks:
+            res[f"block{i}_head"] = f32(hs[i][:, :4])
+            res[f"block{i}_mid"] = f32(hs[i][:, 100:102])
+            if tail:
+                res[f"block{i}_tail"] = f32(hs[i][:, -2:])
+        del model
+        if bf16:
+            mb = build_ref(m, cfg, cast_dtype=torch.bfloat16, variant="sharp")
+            with torch.no_grad():
+                res["image_features_refbf16"] = f32(mb.encode_image(img.to(torch.bfloat16)))
+                res["text_features_refbf16"] = f32(mb.encode_text(tok))
+        off = res["image_image_cos"][~np.eye(nimg, dtype=bool)]
+        print(f"  {pname}: max cos between different images {off.max():.4f}")
+        return res
+
+    np.savez_compressed(os.path.join(outdir, "tiny16_160_sharp.npz"), **run("vit-tiny-patch16-160", 160, 4, [0, 5, 11], 41, True))
+    np.savez_compressed(os.path.join(outdir, "large14_224_sharp.npz"),
+                        **run("vit-large-patch14-224", 224, 4, [0, 11, 23], 42, True, bf16=True))
+    np.savez_compressed(os.path.join(outdir, "small8_384_sharp.npz"),
+                        **run("vit-small-patch8-384", 384, 2, [0, 11], 43, True, text=False))
 
 
 def gen_large(m, lossmod, out):
@@ -446,6 +518,7 @@ def main():
         "tiny": lambda: gen_tiny(m, lossmod, os.path.join(HERE, "tiny16_160.npz")),
         "testcat": lambda: gen_testcat(m, a.ref, os.path.join(HERE, "tiny16_160_testcat.npz")),
         "large": lambda: gen_large(m, lossmod, os.path.join(HERE, "large14_224.npz")),
+        "sharp": lambda: gen_sharp(m, lossmod, HERE),
         "small": lambda: gen_small(m, os.path.join(HERE, "small8_384.npz")),
         "cliploss": lambda: gen_cliploss(lossmod, a.ref, os.path.join(HERE, "cliploss_ws.npz")),
         "preprocess": lambda: gen_preprocess(a.ref, os.path.join(HERE, "preprocess.npz")),

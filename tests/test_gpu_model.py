@@ -74,25 +74,120 @@ def test_tiny_exploded_forward_like_ov_zero_shot_test(tiny):
     assert one_minus_cos(t, g["text_features"]) < COS_TOL
 
 
-def test_tiny_testcat_table_topk(tiny):
+TOPK_GAP = 5e-2     # tests/golden/make_golden.py builds the table so that the reference's neighbouring ranks are this far apart
+
+
+def _leading_ranks(row, gap):
+    srt = np.sort(row)[::-1]
+    k = 0
+    while k + 1 < len(srt) and srt[k] - srt[k + 1] > gap:
+        k += 1
+    return k
+
+
+@pytest.fixture(scope="module")
+def tiny_sharp():
+    cfg = preset("vit-tiny-patch16-160")
+    return create_model(cfg, device=DEV, state_dict=synth.make_state_dict(cfg, 0, "sharp"))
+
+
+def test_tiny_testcat_table_topk(tiny_sharp):
+    """ov-zero-shot-test.py:176-192 on the 5 testcat images x 9 caption rows ('sharp' weights): the whole per-image ranking and the
+    per-text best image must equal the reference's (north_star: top-k indices bit-exact).  Not vacuous: the number of ranks the
+    reference decides with margin is asserted first (the fixture gives all 8 per row)."""
+    m = tiny_sharp
     g = golden("tiny16_160_testcat.npz")
+    assert str(g["variant"]) == "sharp"
     img = torch.from_numpy(g["images"].astype(np.float32)).to(DEV)
     tok = torch.from_numpy(g["tokens"]).to(DEV)
-    tf = tiny.encode_text(tok, normalize=True)
+    tf = m.encode_text(tok, normalize=True)
     cos = []
     for i in range(img.shape[0]):                               # batch 1 per image, as the script does
-        cos.append(logits(tiny.encode_image(img[i:i + 1], normalize=True), tf)[0])
+        cos.append(logits(m.encode_image(img[i:i + 1], normalize=True), tf)[0])
     cos = torch.stack(cos).cpu()
-    np.testing.assert_allclose(cos.numpy(), g["cosine"], atol=1e-2)
     ref = g["cosine"]
+    # cosine budget of the bf16 path: two embeddings each within 1e-3 cosine (angle 0.045 rad) of the reference
+    assert np.abs(cos.numpy() - ref).max() < TOPK_GAP / 2
     order = cos.argsort(dim=-1, descending=True).numpy()
     for r in range(ref.shape[0]):
-        # top-k order must match wherever the reference's neighbouring gaps exceed the bf16 budget
-        srt = np.sort(ref[r])[::-1]
-        k = 0
-        while k + 1 < len(srt) and srt[k] - srt[k + 1] > 2e-2:
-            k += 1
-        assert np.array_equal(order[r][:k], g["argsort"][r][:k])
+        k = _leading_ranks(ref[r], TOPK_GAP)
+        assert k >= 3, f"fixture row {r} decides only {k} ranks with margin"
+        assert np.array_equal(order[r][:k], g["argsort"][r][:k]), f"row {r}: top-{k} order differs"
+        if k == ref.shape[1] - 1:
+            assert np.array_equal(order[r], g["argsort"][r])
+    probs = (float(m.logit_scale.exp()) * cos).softmax(dim=-1)
+    assert np.array_equal(probs.argmax(dim=-1).numpy(), g["best"])
+    np.testing.assert_allclose(probs.numpy(), g["probs"], atol=0.05)
+
+
+def _block_prefix_tokens(m, img, upto):
+    """Residual stream of the HIP vision tower after block `upto` (the same launches encode_image makes, stopped early)."""
+    from openvision_amd.model import _run_blocks
+    tok = m.visual._embed_tokens(img.contiguous())
+    return _run_blocks(list(m.visual.transformer.resblocks[: upto + 1]), tok).float().cpu().numpy()
+
+
+# bf16 residual stream (8 mantissa bits, re-rounded after each of the two residual adds per block) against the reference's fp32
+# stream: budget per element = REL * rms of the stream at that depth * sqrt(blocks passed), checked as max-abs and as rms
+def _check_stream(got, want, depth, what, rel_max=0.02, rel_rms=0.004):
+    rms = float(np.sqrt((want.astype(np.float64) ** 2).mean()))
+    err = np.abs(got - want)
+    lim = rms * np.sqrt(depth + 1)
+    assert err.max() < rel_max * lim * 4 and float(np.sqrt((err ** 2).mean())) < rel_rms * lim * 4, \
+        f"{what}: max {err.max():.4f} rms {np.sqrt((err ** 2).mean()):.5f} (stream rms {rms:.3f})"
+
+
+def _sharp_case(name, pname, blocks, text=True):
+    cfg = preset(pname)
+    m = create_model(cfg, device=DEV, state_dict=synth.make_state_dict(cfg, 0, "sharp"))
+    g = golden(name)
+    img = torch.from_numpy(g["images"].astype(np.float32)).to(DEV)
+    n = img.shape[0]
+    fi = m.encode_image(img)
+    oc = one_minus_cos(fi, g["image_features"])
+    assert oc < COS_TOL, f"{name}: image embeddings 1-cos {oc:.2e}"
+    # the gate discriminates: every OTHER image's reference embedding is > 100x the tolerance away
+    ni = torch.nn.functional.normalize(fi.cpu(), dim=-1)
+    nr = torch.nn.functional.normalize(torch.from_numpy(g["image_features"]), dim=-1)
+    cross = (ni @ nr.T).numpy()
+    assert (1 - cross[~np.eye(n, dtype=bool)]).min() > 0.1
+    assert np.array_equal(cross.argmax(axis=1), np.arange(n))
+    for b in blocks:
+        tokens = _block_prefix_tokens(m, img, b)
+        _check_stream(tokens[:, :4], g[f"block{b}_head"], b, f"{name} block {b} head")
+        _check_stream(tokens[:, 100:102], g[f"block{b}_mid"], b, f"{name} block {b} mid")
+        _check_stream(tokens[:, -2:], g[f"block{b}_tail"], b, f"{name} block {b} tail")
+    if text:
+        tok = torch.from_numpy(g["tokens"]).to(DEV)
+        ft = m.encode_text(tok)
+        assert one_minus_cos(ft, g["text_features"]) < COS_TOL
+        c = logits(m.encode_image(img, normalize=True), m.encode_text(tok, normalize=True)).cpu().numpy()
+        assert np.abs(c - g["cosine"]).max() < TOPK_GAP / 2
+        for r in range(n):
+            k = _leading_ranks(g["cosine"][r], TOPK_GAP)
+            assert np.array_equal(np.argsort(-c[r], kind="stable")[:k], g["argsort"][r][:k])
+        if "loss" in g.files:
+            a, b_, s_ = m(img, tok)
+            assert abs(float(ClipLoss()(a, b_, s_)) - float(g["loss"])) < 0.05
+    return m, g
+
+
+def test_tiny_sharp_blocks_and_features():
+    _sharp_case("tiny16_160_sharp.npz", "vit-tiny-patch16-160", [0, 5, 11])
+
+
+@pytest.mark.timeout(900)
+def test_large14_224_sharp_blocks_and_features():
+    """Headline size on discriminating inputs: pooled embeddings AND the residual stream after blocks 0 / 11 / 23 against the
+    reference's fp32 activations (the reference's own bf16 mode sits up to 8.6e-4 from its fp32 mode on these weights)."""
+    m, g = _sharp_case("large14_224_sharp.npz", "vit-large-patch14-224", [0, 11, 23])
+    img = torch.from_numpy(g["images"].astype(np.float32)).to(DEV)
+    assert one_minus_cos(m.encode_image(img), g["image_features_refbf16"]) < 2 * COS_TOL
+
+
+@pytest.mark.timeout(900)
+def test_small8_384_sharp_blocks_and_features():
+    _sharp_case("small8_384_sharp.npz", "vit-small-patch8-384", [0, 11], text=False)
 
 
 def test_batch_invariance_and_determinism(tiny):

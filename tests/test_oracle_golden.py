@@ -61,9 +61,11 @@ def test_tiny_text_and_forward(tiny):
     close(R.clip_loss(ni, nt, s), g["loss"], 1e-5)
 
 
-def test_tiny_testcat_zero_shot_table(tiny):
-    cfg, sd = tiny
+def test_tiny_testcat_zero_shot_table():
+    cfg = ovcfg.preset("vit-tiny-patch16-160")
+    sd = synth.make_state_dict(cfg, 0, "sharp")
     g = golden("tiny16_160_testcat.npz")
+    assert str(g["variant"]) == "sharp"
     img, tok = T(g["images"].astype(np.float32)), T(g["tokens"])
     cos, probs, order = R.zero_shot_table(R.encode_image(img, sd, cfg), R.encode_text(tok, sd, cfg),
                                           sd["logit_scale"])
@@ -100,6 +102,37 @@ def test_small8_384_features():
     feat, tokens = R.vision_forward(T(g["images"].astype(np.float32)), sd, cfg["vision_cfg"], return_tokens=True)
     close(tokens[:, :4], g["block11_head"], 5e-4, 1e-4)
     close(feat, g["image_features"], 2e-4, 1e-4)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("name,preset,last", [("tiny16_160_sharp.npz", "vit-tiny-patch16-160", 11),
+                                               ("large14_224_sharp.npz", "vit-large-patch14-224", 23),
+                                               ("small8_384_sharp.npz", "vit-small-patch8-384", 11)])
+def test_sharp_fixtures_discriminate_and_pin_the_oracle(name, preset, last):
+    """The discriminating fixtures ('sharp' weights, structured images): the reference's outputs for DIFFERENT inputs are far
+    apart (so a wrong row / input-independent encoder cannot pass the cosine gate), and the oracle reproduces them."""
+    cfg = ovcfg.preset(preset)
+    sd = synth.make_state_dict(cfg, 0, "sharp")
+    g = golden(name)
+    n = g["images"].shape[0]
+    off = g["image_image_cos"][~np.eye(n, dtype=bool)]
+    assert off.max() < 0.9                                  # different images: 1 - cos > 0.1 = 100x the 1e-3 gate
+    img = T(g["images"].astype(np.float32))
+    feat, tokens = R.vision_forward(img, sd, cfg["vision_cfg"], return_tokens=True)
+    close(tokens[:, :4], g[f"block{last}_head"], 2e-3, 2e-4)
+    close(tokens[:, -2:], g[f"block{last}_tail"], 2e-3, 2e-4)
+    cos = torch.nn.functional.cosine_similarity(feat, T(g["image_features"]))
+    assert float((1 - cos).max()) < 1e-6
+    x = R.resblock(R.patch_embed(img, sd, cfg["vision_cfg"]["patch_size"]), sd, "visual.transformer.resblocks.0.",
+                   cfg["vision_cfg"]["width"] // cfg["vision_cfg"]["head_width"], False)
+    close(x[:, :4], g["block0_head"], 1e-4, 1e-4)
+    if "text_features" in g.files:
+        tf = R.encode_text(T(g["tokens"]), sd, cfg)
+        assert float((1 - torch.nn.functional.cosine_similarity(tf, T(g["text_features"]))).max()) < 1e-6
+        offt = g["text_text_cos"][~np.eye(tf.shape[0], dtype=bool)]
+        assert offt.max() < 0.95
+        c = R.l2_normalize(feat) @ R.l2_normalize(tf).T
+        close(c, g["cosine"], 2e-5)
 
 
 def test_cliploss_local_losses_match_reference_ranks():
