@@ -7,8 +7,10 @@ N > 1, and the fused InfoNCE on the local [b, N*b] logit strips.  Pure data para
 (per-GPU batch fixed).  Prints ONE JSON line on rank 0.
 
     python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus N --steps K --warmup W          # launches its own N ranks (one process per GPU) and relays rank 0's line
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W             # the same, under an external launcher
+    python bench.py --gpus 2 --dry-run-gloo                # CPU rehearsal of the N-rank plumbing (gloo; no kernels, no throughput)
 """
 from __future__ import annotations
 
@@ -24,9 +26,6 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL; must be set before the HIP runtime starts
-
-import torch                      # noqa: E402
-import torch.distributed as dist  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0         # dense MFMA bf16, /opt/skills/guides/MI355X_MICROARCH.md (chip-level parameters)
 PEAK_FP8_TFLOPS = 5000.0         # dense MX-scaled fp8 MFMA, same guide
@@ -47,7 +46,85 @@ def parse():
                     help="encode this many micro-batches of --batch pairs per step, one InfoNCE over all of them "
                          "(config #5: 16 x 256 per GPU = 32k pairs on 8 GPUs)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp8"], help="GEMM operand precision of the block stacks")
+    ap.add_argument("--dry-run-gloo", action="store_true",
+                    help="CPU rehearsal of the multi-rank plumbing (launcher, rendezvous, rank-ordered all-gather, barrier-fenced "
+                         "timing, max over ranks) on the gloo backend: runs no kernel and reports no throughput")
     return ap.parse_args()
+
+
+def launch_ranks(n: int) -> int:
+    """`--gpus N` without a launcher around us: start N fresh ranks (one process per GPU) through torch.distributed.run and relay
+    rank 0's single JSON line.  Runs BEFORE torch is imported: the parent never touches a device.  Returns the exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "4"))
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    if p.returncode != 0 or not lines:
+        sys.stderr.write(p.stdout)
+        sys.stderr.write(f"bench.py: the {n}-rank run failed (exit code {p.returncode})\n")
+        return p.returncode or 1
+    print(lines[-1], flush=True)
+    return 0
+
+
+def dry_run_gloo(a, result_out) -> None:
+    """The N-rank host path without a GPU: what a rank does around the kernels (rendezvous from the launcher's environment,
+    contiguous batch shard, the packed rank-ordered all-gather of openvision_amd.loss.gather_features, barrier-fenced timing, max
+    over ranks, one JSON line on rank 0).  No throughput is reported: nothing is computed."""
+    import torch
+    import torch.distributed as dist
+    from openvision_amd.loss import gather_features
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        dist.init_process_group("gloo")
+    b, e = 8, 16
+    g = torch.Generator().manual_seed(0)
+    full_i, full_t = torch.randn(world * b, e, generator=g), torch.randn(world * b, e, generator=g)
+    li, lt = full_i[rank * b:(rank + 1) * b].contiguous(), full_t[rank * b:(rank + 1) * b].contiguous()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+    ok = True
+    for _ in range(a.warmup):
+        gather_features(li, lt, True, False, rank, world)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        ai, at = gather_features(li, lt, True, False, rank, world)
+        ok = ok and bool(torch.equal(ai, full_i) and torch.equal(at, full_t))
+    fence()
+    dt = torch.tensor([time.perf_counter() - t0, 0.0 if ok else 1.0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        result_out.write(json.dumps({"metric": "dry run (gloo, CPU): multi-rank plumbing only", "value": None, "unit": None,
+                                     "n_gpus": 0, "n_ranks_seen": dist.get_world_size() if world > 1 else 1,
+                                     "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(float(dt[0]) / a.steps * 1e3, 3),
+                                     "gather_rank_ordered": bool(dt[1] == 0), "scaling": "weak", "data": "synthetic",
+                                     "dry_run": True}) + "\n")
+        result_out.flush()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if dt[1] != 0:
+        raise SystemExit("gathered rows are not in rank order")
+
+
+def cpu_model() -> str:
+    try:
+        for l in open("/proc/cpuinfo"):
+            if l.startswith("model name"):
+                return l.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
 
 
 def class_work(cfg, b):
@@ -87,12 +164,14 @@ def host_cores() -> int:
 
 def cpu_baseline(cfg, sd, budget_s: float):
     """The oracle (CPU restatement of the reference path, plain torch fp32 aten kernels) on a bounded sample of the
-    SAME workload: image+text towers + InfoNCE at batch 4, >= budget_s seconds of work after one warm-up."""
+    SAME workload (SURVEY.md section 8d protocol): image+text towers + InfoNCE at batch 8 (64 for the tiny model), 3 warm-up and
+    >= 5 timed iterations, about budget_s seconds of work, all granted host cores."""
+    import torch
     from openvision_amd import synth
     from oracle import clip_ref as R
     cores = host_cores()
     torch.set_num_threads(cores)
-    b = 4
+    b = 64 if cfg["vision_cfg"]["width"] < 256 else 8
     img = synth.make_images(b, cfg["vision_cfg"]["image_size"], seed=123)
     tok = synth.make_captions(b, cfg["text_cfg"]["context_length"], cfg["text_cfg"]["vocab_size"], seed=123)
     sdf = {k: v.float() for k, v in sd.items()}
@@ -101,21 +180,24 @@ def cpu_baseline(cfg, sd, budget_s: float):
         with torch.no_grad():
             ni, nt, s = R.clip_forward(img, tok, sdf, cfg)
             return R.clip_loss(ni, nt, s)
-    step()
+    for _ in range(3):
+        step()
     n, t0 = 0, time.perf_counter()
     while True:
         step()
         n += 1
         dt = time.perf_counter() - t0
-        if dt >= budget_s or n >= 50:
+        if (dt >= budget_s and n >= 5) or n >= 50:
             break
-    return {"value": round(n * b / dt, 3), "unit": "images/sec", "cores": cores, "kind": "port",
+    return {"value": round(n * b / dt, 3), "unit": "images/sec", "cores": cores, "cpu": cpu_model(), "kind": "port",
             "sample": f"{n} iterations of batch {b} (image+text towers + InfoNCE, fp32 torch CPU ops via oracle/clip_ref.py), "
-                      f"{dt:.1f} s after 1 warm-up"}
+                      f"{dt:.1f} s after 3 warm-ups"}
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(launch_ranks(a.gpus))           # parent of the ranks: never imports torch, never touches a device
     # stdout carries exactly ONE line, the JSON result: libraries that print to fd 1 (RCCL's banner when a communicator is
     # created, ...) are sent to stderr for the rest of the run; the result goes to a private duplicate of the original stdout.
     sys.stdout.flush()
@@ -124,10 +206,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
-        a.gpus = world
+    if a.dry_run_gloo:
+        return dry_run_gloo(a, result_out)
+    import torch
+    import torch.distributed as dist
+    a.gpus = world                                        # under a launcher the world it made is authoritative
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -246,7 +329,7 @@ def main():
                       else f"images/sec (node) {a.model} fwd+InfoNCE",
             "value": round(world * b * mb * a.steps / dt, 2),
             "unit": "images/sec",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "n_gpus": world, "n_ranks_seen": dist.get_world_size() if world > 1 else 1, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.precision, "data": "synthetic",

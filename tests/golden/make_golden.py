@@ -198,7 +198,7 @@ def gen_sharp(m, lossmod, outdir):
     """Discriminating fixtures: 'sharp' formula weights + structured images (synth.make_structured_images), so that a wrong
     row, a wrong image or an input-independent encoder FAILS the 1e-3 cosine gate (on the v1 weights two different images sit
     at cos 0.992 of each other).  Per-block residual-stream slices are kept for the HIP path's block-level comparison."""
-    def run(pname, size, nimg, blocks, seed, tail, text=True, bf16=False):
+    def run(pname, size, nimg, blocks, seed, tail, text=True):
         cfg = ovcfg.preset(pname)
         model = build_ref(m, cfg, variant="sharp")
         img = synth.make_structured_images(nimg, size, seed=seed).half().float()      # stored as fp16
@@ -224,10 +224,17 @@ def gen_sharp(m, lossmod, outdir):
             if tail:
                 res[f"block{i}_tail"] = f32(hs[i][:, -2:])
         del model
-        if bf16:
-            mb = build_ref(m, cfg, cast_dtype=torch.bfloat16, variant="sharp")
-            with torch.no_grad():
-                res["image_features_refbf16"] = f32(mb.encode_image(img.to(torch.bfloat16)))
+        # the reference's own bf16 mode (factory.py:275-296) on the same inputs: its distance from the fp32 run IS the bf16 budget
+        # of these weights, per block slice and for the embeddings
+        mb = build_ref(m, cfg, cast_dtype=torch.bfloat16, variant="sharp")
+        hb = tokens_after_blocks(mb, img.to(torch.bfloat16), blocks)
+        for i in blocks:
+            res[f"block{i}_head_refbf16"] = f32(hb[i][:, :4])
+            res[f"block{i}_mid_refbf16"] = f32(hb[i][:, 100:102])
+            res[f"block{i}_tail_refbf16"] = f32(hb[i][:, -2:])
+        with torch.no_grad():
+            res["image_features_refbf16"] = f32(mb.encode_image(img.to(torch.bfloat16)))
+            if text:
                 res["text_features_refbf16"] = f32(mb.encode_text(tok))
         off = res["image_image_cos"][~np.eye(nimg, dtype=bool)]
         print(f"  {pname}: max cos between different images {off.max():.4f}")
@@ -235,7 +242,7 @@ def gen_sharp(m, lossmod, outdir):
 
     np.savez_compressed(os.path.join(outdir, "tiny16_160_sharp.npz"), **run("vit-tiny-patch16-160", 160, 4, [0, 5, 11], 41, True))
     np.savez_compressed(os.path.join(outdir, "large14_224_sharp.npz"),
-                        **run("vit-large-patch14-224", 224, 4, [0, 11, 23], 42, True, bf16=True))
+                        **run("vit-large-patch14-224", 224, 4, [0, 11, 23], 42, True))
     np.savez_compressed(os.path.join(outdir, "small8_384_sharp.npz"),
                         **run("vit-small-patch8-384", 384, 2, [0, 11], 43, True, text=False))
 

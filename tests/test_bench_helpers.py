@@ -32,3 +32,32 @@ def test_class_work_matches_model_flops(bench, name):
 def test_host_cores_is_sane(bench):
     n = bench.host_cores()
     assert 1 <= n <= 16
+
+
+def test_bench_launches_its_own_ranks_gloo_dry_run():
+    """`python bench.py --gpus 2` with no launcher around it must start 2 ranks itself, relay exactly one JSON line and report the
+    world it really ran in (rehearsed on the CPU: gloo, no kernels).  The same launcher code path starts the RCCL ranks."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-gloo", "--steps", "3", "--warmup", "1"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_ranks_seen"] == 2 and out["gather_rank_ordered"] is True and out["dry_run"] is True and out["steps"] == 3
+
+
+def test_bench_launcher_propagates_rank_failure():
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    # two real ranks in a container without a GPU: every rank fails at device selection -> the parent must exit non-zero, no JSON
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--cpu-seconds", "0"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=300)
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs present: the run succeeds")
+    assert p.returncode != 0 and not [l for l in p.stdout.splitlines() if l.startswith("{")]

@@ -127,14 +127,18 @@ def _block_prefix_tokens(m, img, upto):
     return _run_blocks(list(m.visual.transformer.resblocks[: upto + 1]), tok).float().cpu().numpy()
 
 
-# bf16 residual stream (8 mantissa bits, re-rounded after each of the two residual adds per block) against the reference's fp32
-# stream: budget per element = REL * rms of the stream at that depth * sqrt(blocks passed), checked as max-abs and as rms
-def _check_stream(got, want, depth, what, rel_max=0.02, rel_rms=0.004):
+# Budget of the bf16 residual stream against the reference's fp32 stream: the distance of the REFERENCE'S OWN bf16 mode
+# (factory.py:275-296, run by make_golden.py on the same inputs and stored beside the fp32 slices) from its fp32 run.  On the sharp
+# weights the per-token stream is ill-conditioned (peaked attention: rms error 0.29 of a stream rms 2.75 after 24 blocks in the
+# reference's bf16 mode) while the pooled embedding is not.  The HIP path must be no further away than 1.3x that (+ 0.5 % of the
+# stream rms), as rms over the slice, and within 2x of its worst element.
+def _check_stream(got, want, ref_bf16, what):
     rms = float(np.sqrt((want.astype(np.float64) ** 2).mean()))
-    err = np.abs(got - want)
-    lim = rms * np.sqrt(depth + 1)
-    assert err.max() < rel_max * lim * 4 and float(np.sqrt((err ** 2).mean())) < rel_rms * lim * 4, \
-        f"{what}: max {err.max():.4f} rms {np.sqrt((err ** 2).mean()):.5f} (stream rms {rms:.3f})"
+    e_hip, e_ref = np.abs(got - want), np.abs(ref_bf16 - want)
+    r_hip, r_ref = float(np.sqrt((e_hip ** 2).mean())), float(np.sqrt((e_ref ** 2).mean()))
+    assert r_hip < 1.3 * r_ref + 0.005 * rms and e_hip.max() < 2.0 * e_ref.max() + 0.02 * rms, \
+        f"{what}: rms err {r_hip:.5f} (reference bf16 mode {r_ref:.5f}), max {e_hip.max():.4f} ({e_ref.max():.4f}), stream rms {rms:.3f}"
+    return r_hip, r_ref
 
 
 def _sharp_case(name, pname, blocks, text=True):
@@ -154,9 +158,9 @@ def _sharp_case(name, pname, blocks, text=True):
     assert np.array_equal(cross.argmax(axis=1), np.arange(n))
     for b in blocks:
         tokens = _block_prefix_tokens(m, img, b)
-        _check_stream(tokens[:, :4], g[f"block{b}_head"], b, f"{name} block {b} head")
-        _check_stream(tokens[:, 100:102], g[f"block{b}_mid"], b, f"{name} block {b} mid")
-        _check_stream(tokens[:, -2:], g[f"block{b}_tail"], b, f"{name} block {b} tail")
+        for part, sl in (("head", slice(0, 4)), ("mid", slice(100, 102)), ("tail", slice(-2, None))):
+            r = _check_stream(tokens[:, sl], g[f"block{b}_{part}"], g[f"block{b}_{part}_refbf16"], f"{name} block {b} {part}")
+            print(f"{name} block {b} {part}: rms err HIP {r[0]:.5f} / reference bf16 mode {r[1]:.5f}")
     if text:
         tok = torch.from_numpy(g["tokens"]).to(DEV)
         ft = m.encode_text(tok)
@@ -179,7 +183,7 @@ def test_tiny_sharp_blocks_and_features():
 @pytest.mark.timeout(900)
 def test_large14_224_sharp_blocks_and_features():
     """Headline size on discriminating inputs: pooled embeddings AND the residual stream after blocks 0 / 11 / 23 against the
-    reference's fp32 activations (the reference's own bf16 mode sits up to 8.6e-4 from its fp32 mode on these weights)."""
+    reference's fp32 activations (the reference's own bf16 mode sits up to 8.6e-4 (1 - cos) from its fp32 mode on these weights)."""
     m, g = _sharp_case("large14_224_sharp.npz", "vit-large-patch14-224", [0, 11, 23])
     img = torch.from_numpy(g["images"].astype(np.float32)).to(DEV)
     assert one_minus_cos(m.encode_image(img), g["image_features_refbf16"]) < 2 * COS_TOL
