@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define OV_ABI_VERSION 1
+#define OV_ABI_VERSION 2       /* 2: logit scale / upstream loss gradient are device scalars (ov_clip_loss*, ov_logits) */
 
 typedef void* ov_stream_t;            /* hipStream_t */
 typedef uint16_t ov_bf16;             /* raw bfloat16 bits */
@@ -140,8 +140,9 @@ int ov_convert(const void* src, int src_dtype, int64_t lds, void* dst, int dst_d
 int ov_l2norm(const void* x, int x_dtype, int64_t ldx, float* y, int64_t ldy, int64_t rows, int E,
               ov_stream_t stream);
 
-/* out[i, j] = scale * <X[i,:], Y[j,:]>  fp32 in/out (CLIP.get_logits: model.py:286-293).  E % 8 == 0. */
-int ov_logits(const float* X, const float* Y, float* out, int64_t ldo, int n1, int n2, int E, float scale,
+/* out[i, j] = scale * (*scale_dev) * <X[i,:], Y[j,:]>  fp32 in/out (CLIP.get_logits: model.py:286-293).  E % 8 == 0.
+ * scale_dev: optional device scalar (NULL = 1): exp(logit_scale) stays on the device, as in the reference (model.py:288). */
+int ov_logits(const float* X, const float* Y, float* out, int64_t ldo, int n1, int n2, int E, float scale, const float* scale_dev,
               ov_stream_t stream);
 
 /* ov_attention with the output written as e4m3 bytes out8[B*L, H*64] (ld_out in bytes) under the static scale 2 * (*out_amax) / 448
@@ -203,25 +204,27 @@ int ov_topk(const float* x, int64_t ldx, int rows, int cols, int k, int largest,
 /* Local-strip InfoNCE (ClipLoss with local_loss semantics; world_size 1 = plain ClipLoss).
  *   img, txt      : this rank's L2-normalised embeddings [b, E] fp32
  *   all_img/all_txt: gathered embeddings [N, E] fp32 in rank order (== img/txt when N == b)
+ *   logit_scale   : DEVICE scalar, the multiplier exp(CLIP.logit_scale) (model.py:315) -- ABI 2: it never crosses the host, so
+ *                   the step enqueues without a stream drain (the reference keeps it on the device too: loss.py:120-131)
  *   labels are i + label_offset (label_offset = b * rank, loss.py:93-94)
  *   loss_out[0] = (CE(scale*img@all_txt^T) + CE(scale*txt@all_img^T)) / 2      (fp32, device)
  *   lse_out (optional, may be NULL): [4, b] fp32 = lse_img, diag_img, lse_txt, diag_txt
  * workspace: ov_clip_loss_workspace_bytes(b, N) bytes. Logits are never materialised. */
 size_t ov_clip_loss_workspace_bytes(int b, int N);
 int ov_clip_loss(const float* img, const float* txt, const float* all_img, const float* all_txt,
-                 int b, int N, int E, float logit_scale, int label_offset, float* loss_out,
+                 int b, int N, int E, const float* logit_scale, int label_offset, float* loss_out,
                  float* lse_out, void* workspace, size_t workspace_bytes, ov_stream_t stream);
 
 /* Backward of ov_clip_loss (loss.py:102-131 differentiated; the reference gets it from autograd): with P = softmax - onehot of
  * each [b, N] strip (recomputed, never materialised; lse_terms = the [4, b] block ov_clip_loss wrote) and c = grad_loss *
- * logit_scale / (2 b):   d_img = c P_i all_txt,  d_txt = c P_t all_img            (local rows, [b, E], always written)
+ * logit_scale / (2 b) (both DEVICE scalars; grad_loss NULL = 1):   d_img = c P_i all_txt,  d_txt = c P_t all_img            (local rows, [b, E], always written)
  *                        d_all_txt = c P_i^T img, d_all_img = c P_t^T txt          (gathered rows, [N, E]; NULL = skip)
  *                        d_scale = grad_loss / (2 b) * sum P .* (x . y)            (device scalar; NULL = skip)
  * The caller routes the gathered-side terms (gather_features, loss.py:19-63: own chunk only, or reduce-scatter when
  * gather_with_grad).  E % 32 == 0, E <= 1152; OV_ERR_UNSUPPORTED otherwise.  Deterministic (no atomics). */
 size_t ov_clip_loss_backward_workspace_bytes(int b, int N);
 int ov_clip_loss_backward(const float* img, const float* txt, const float* all_img, const float* all_txt, int b, int N, int E,
-                          float logit_scale, int label_offset, const float* lse_terms, float grad_loss, float* d_img,
+                          const float* logit_scale, int label_offset, const float* lse_terms, const float* grad_loss, float* d_img,
                           float* d_txt, float* d_all_img, float* d_all_txt, float* d_scale, void* workspace,
                           size_t workspace_bytes, ov_stream_t stream);
 

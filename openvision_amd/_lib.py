@@ -85,13 +85,13 @@ SIGNATURES = {
     "ov_gather_rows": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
     "ov_convert": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_int64, c_int, c_void_p]),
     "ov_l2norm": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p]),
-    "ov_logits": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_float, c_void_p]),
+    "ov_logits": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     "ov_preprocess_image": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
                                     c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "ov_class_mean_normalize": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ov_topk": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ov_clip_loss_workspace_bytes": (c_size_t, [c_int, c_int]),
-    "ov_clip_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p,
+    "ov_clip_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p,
                              c_void_p, c_void_p, c_size_t, c_void_p]),
     "ov_clip_loss_backward_workspace_bytes": (c_size_t, [c_int, c_int]),
     "ov_gemm_batched": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int, c_int,
@@ -115,8 +115,8 @@ SIGNATURES = {
     "ov_block_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t,
                                   c_void_p]),
     "ov_tower_saved_bytes": (c_size_t, [c_void_p, c_int, c_int]),
-    "ov_clip_loss_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p,
-                                      c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "ov_clip_loss_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p,
+                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "ov_profile_enable": (c_int, [C.c_uint, c_int]),
     "ov_profile_read": (c_int, [c_int, C.POINTER(C.c_double), C.POINTER(c_int), C.POINTER(C.c_double)]),
     "ov_debug_gemm_stamps": (c_int, [c_void_p, c_int]),
@@ -138,6 +138,7 @@ SIGNATURES = {
                                c_size_t, c_void_p]),
 }
 
+ABI_VERSION = 2      # include/ovhip.h OV_ABI_VERSION
 _lib = None
 _lock = threading.Lock()
 
@@ -164,7 +165,7 @@ def load() -> C.CDLL:
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)          # AttributeError -> ABI mismatch, fail loudly
             fn.restype, fn.argtypes = res, args
-        if lib.ov_abi_version() != 1:
+        if lib.ov_abi_version() != ABI_VERSION:
             raise OvhipError("libovhip.so ABI version mismatch")
         _lib = lib
     return _lib

@@ -22,18 +22,25 @@ BIN_NAME = "open_clip_pytorch_model.bin"
 SAFETENSORS_NAMES = ("open_clip_model.safetensors", "model.safetensors")
 
 
+def _unwrap(sd):
+    """factory.py:134-147 (load_state_dict): a training checkpoint keeps the weights under 'state_dict'; keys saved from a
+    DistributedDataParallel wrapper carry a 'module.' prefix (decided, as the reference does, by the FIRST key)."""
+    if isinstance(sd, dict) and "state_dict" in sd and isinstance(sd["state_dict"], dict):
+        sd = sd["state_dict"]
+    if sd and next(iter(sd)).startswith("module"):
+        sd = {k[7:]: v for k, v in sd.items()}
+    return sd
+
+
 def read_state_dict(path: str) -> Dict[str, torch.Tensor]:
     for n in SAFETENSORS_NAMES:
         f = os.path.join(path, n)
         if os.path.exists(f):
             from safetensors.torch import load_file
-            return load_file(f, device="cpu")
+            return _unwrap(load_file(f, device="cpu"))
     f = os.path.join(path, BIN_NAME)
     if os.path.exists(f):
-        sd = torch.load(f, map_location="cpu", weights_only=True)
-        if isinstance(sd, dict) and "state_dict" in sd and all(isinstance(k, str) for k in sd["state_dict"]):
-            sd = sd["state_dict"]
-        return sd
+        return _unwrap(torch.load(f, map_location="cpu", weights_only=True))
     raise FileNotFoundError(f"no {BIN_NAME} / {SAFETENSORS_NAMES[0]} under {path}")
 
 

@@ -984,12 +984,13 @@ int attention_impl(const ov_bf16* qkv, int64_t ld_qkv, ov_bf16* out, int64_t ld_
         g.KC = lpad < 256 ? lpad : 256;
         const int nwg = g.nqt < 8 ? g.nqt : 8;
         const size_t smem = (size_t)g.KC * 96 * 4;       // K (KC x 192 B) + V (3 x KC x 64 B)
-        static bool attr3 = false;
-        if (!attr3) {
+        static OvPerDeviceOnce attr3;
+        const int dev_attr3 = ov_current_device();
+        if (attr3.need(dev_attr3)) {
             hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_generic<96>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                160 * 1024);
             if (e != hipSuccess) return OV_ERR_HIP - (int)e;
-            attr3 = true;
+            attr3.mark(dev_attr3);
         }
         hipLaunchKernelGGL(attn_fwd_generic<96>, dim3((unsigned)(B * H), (unsigned)((g.nqt + nwg - 1) / nwg)), dim3(nwg * 64), smem,
                            (hipStream_t)stream, g, hd);
@@ -1010,8 +1011,9 @@ int attention_impl(const ov_bf16* qkv, int64_t ld_qkv, ov_bf16* out, int64_t ld_
         p.qkv = qkv; p.ldq = ld_qkv; p.out = out; p.ldo = ld_out;
         p.L = L; p.H = H; p.nqt = a.nqt; p.KC = lp; p.nheads = B * H; p.scale_log2 = a.scale_log2; p.out_amax = out_amax; p.amax_next = amax_next;
         { static int lk = -1; if (lk < 0) { const char* e = getenv("OVHIP_ATTN_LONEKEY"); lk = (e && e[0] == '0') ? 0 : 1; } p.lone_valu = lk; }
-        static bool attr2 = false;
-        if (!attr2) {
+        static OvPerDeviceOnce attr2;
+        const int dev_attr2 = ov_current_device();
+        if (attr2.need(dev_attr2)) {
             hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_hd64_persist<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                160 * 1024);
             if (e == hipSuccess)
@@ -1021,15 +1023,9 @@ int attention_impl(const ov_bf16* qkv, int64_t ld_qkv, ov_bf16* out, int64_t ld_
             if (e == hipSuccess)
                 e = hipFuncSetAttribute((const void*)attn_fwd_hd64_persist<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return OV_ERR_HIP - (int)e;
-            attr2 = true;
+            attr2.mark(dev_attr2);
         }
-        static int ncu = 0;
-        if (ncu == 0) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-                   prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-        }
+        const int ncu = ov_num_cus();
         const size_t smem = (size_t)2 * lp * 256;
         int per_cu = (int)((160 * 1024) / smem);                  // workgroups per CU by LDS ...
         const int by_waves = (a.nqt <= 8 ? 8 : 12) / a.nqt;       // ... and by waves (2 per SIMD for the DEEP variant, else 3)
@@ -1055,13 +1051,14 @@ int attention_impl(const ov_bf16* qkv, int64_t ld_qkv, ov_bf16* out, int64_t ld_
         sa.scale_log2 = a.scale_log2;
         sa.out_amax = out_amax;
         sa.amax_next = amax_next;
-        static bool attr4 = false;
-        if (!attr4) {
+        static OvPerDeviceOnce attr4;
+        const int dev_attr4 = ov_current_device();
+        if (attr4.need(dev_attr4)) {
             hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_hd64_stream<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e == hipSuccess)
                 e = hipFuncSetAttribute((const void*)attn_fwd_hd64_stream<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return OV_ERR_HIP - (int)e;
-            attr4 = true;
+            attr4.mark(dev_attr4);
         }
         const int64_t heads8 = ((int64_t)sa.nheads + 7) / 8 * 8;             // whole rounds of 8 XCDs; surplus ids exit at once
         const int64_t nwg = heads8 * sa.nqb;
@@ -1077,12 +1074,13 @@ int attention_impl(const ov_bf16* qkv, int64_t ld_qkv, ov_bf16* out, int64_t ld_
     else { a.KC = 256; nw = 8; }
     const int gy = (a.nqt + nw - 1) / nw;
     const size_t smem = (size_t)a.KC * 256;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static OvPerDeviceOnce attr_set;
+        const int dev_attr_set = ov_current_device();
+    if (attr_set.need(dev_attr_set)) {
         hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_hd64, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            160 * 1024);
         if (e != hipSuccess) return OV_ERR_HIP - (int)e;
-        attr_set = true;
+        attr_set.mark(dev_attr_set);
     }
     hipLaunchKernelGGL(attn_fwd_hd64, dim3((unsigned)(B * H), (unsigned)gy), dim3(nw * 64), smem,
                        (hipStream_t)stream, a);

@@ -534,13 +534,14 @@ extern "C" size_t ov_attention_backward_workspace_bytes(int B, int L, int H, int
 namespace {
 template <int NDH>
 int launch_stream(const AttnBwdSArgs& g, int B, hipStream_t st) {
-    static bool attr = false;
+    static OvPerDeviceOnce attr;
+    const int dev = ov_current_device();
     const size_t smem = (size_t)2 * Stream<NDH>::IMG + (size_t)2 * CH * sizeof(float);
-    if (!attr) {
+    if (attr.need(dev)) {
         hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_stream_q<NDH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_stream_kv<NDH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return ov_hip(e);
-        attr = true;
+        attr.mark(dev);
     }
     const dim3 grid((unsigned)(B * g.a.H * g.nblk));
     hipLaunchKernelGGL(attn_bwd_stream_q<NDH>, grid, dim3(512), smem, st, g);
@@ -566,11 +567,12 @@ extern "C" int ov_attention_backward(const ov_bf16* qkv, int64_t ld_qkv, const o
     a.L = L; a.H = H; a.KC = (L + 31) / 32 * 32;
     a.scale = scale; a.scale_log2 = scale * 1.4426950408889634f;
     if (hd == 64 && L <= 288) {                                 // Q, K, V, dO of a head resident in LDS
-        static bool attr = false;
-        if (!attr) {
+        static OvPerDeviceOnce attr;
+        const int dev = ov_current_device();
+        if (attr.need(dev)) {
             hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_hd64, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return ov_hip(e);
-            attr = true;
+            attr.mark(dev);
         }
         const size_t smem = (size_t)4 * a.KC * 128 + (size_t)2 * a.KC * sizeof(float);
         hipLaunchKernelGGL(attn_bwd_hd64, dim3((unsigned)(B * H)), dim3((unsigned)(a.KC / 32 * 64)), smem, (hipStream_t)stream, a);

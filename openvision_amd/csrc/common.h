@@ -22,6 +22,31 @@ typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 
 static inline int ov_hip(hipError_t e) { return e == hipSuccess ? OV_OK : OV_ERR_HIP - (int)e; }
 
+// ---- per-device host state: function attributes (hipFuncSetAttribute) and device properties belong to ONE device; a process
+// may drive several (one host thread each).  Device ids beyond OV_MAX_DEVICES - 1 share the last slot's "not yet done" answer
+// (the attribute is then set on every launch: correct, just slower).
+#define OV_MAX_DEVICES 64
+static inline int ov_current_device() {
+    int d = 0;
+    return hipGetDevice(&d) == hipSuccess && d >= 0 ? d : 0;
+}
+struct OvPerDeviceOnce {
+    unsigned long long done = 0;      // bit d: set for device d (benign race: the guarded calls are idempotent)
+    bool need(int dev) const { return dev >= OV_MAX_DEVICES || !((__atomic_load_n(&done, __ATOMIC_ACQUIRE) >> dev) & 1ull); }
+    void mark(int dev) { if (dev < OV_MAX_DEVICES) __atomic_fetch_or(&done, 1ull << dev, __ATOMIC_RELEASE); }
+};
+static inline int ov_num_cus() {
+    static int cache[OV_MAX_DEVICES] = {};
+    const int dev = ov_current_device();
+    int n = dev < OV_MAX_DEVICES ? __atomic_load_n(&cache[dev], __ATOMIC_RELAXED) : 0;
+    if (n == 0) {
+        hipDeviceProp_t p;
+        n = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+        if (dev < OV_MAX_DEVICES) __atomic_store_n(&cache[dev], n, __ATOMIC_RELAXED);
+    }
+    return n;
+}
+
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short h) {
     return __uint_as_float(((unsigned int)h) << 16);
 }

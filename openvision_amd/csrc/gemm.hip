@@ -724,18 +724,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist(const GemmArgs 
     }
 }
 
-int num_cus() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0;
-        hipDeviceProp_t p;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0)
-            n = p.multiProcessorCount;
-        else
-            n = 256;
-    }
-    return n;
-}
+int num_cus() { return ov_num_cus(); }
 
 thread_local const float* g_colsum = nullptr;      // set by ov_gemm_ln around its call into ov_gemm
 thread_local const float* g_rowstats = nullptr;
@@ -775,8 +764,9 @@ int launch(GemmArgs a, hipStream_t st) {
     // fewer tiles than CUs (pooled heads, the tower's tail images): persistence buys nothing, use the plain launch
     // the persistent kernel also wins on grids somewhat smaller than the chip (one tile per workgroup, but its epilogue starts
     // without global round trips); tiny grids (the tower's tail images) stay on the plain launch
-    static int min_persist = -1;
-    if (min_persist < 0) { const char* e = getenv("OVHIP_GEMM_MINPERSIST"); min_persist = e ? atoi(e) : num_cus(); }
+    static int min_persist_env = -2;
+    if (min_persist_env == -2) { const char* e = getenv("OVHIP_GEMM_MINPERSIST"); min_persist_env = e ? atoi(e) : -1; }
+    const int min_persist = min_persist_env >= 0 ? min_persist_env : num_cus();
     if (var == 0 && (nwg < min_persist || a.K < 3 * BK)) var = 2;
     if (var == 1) {
         hipLaunchKernelGGL(gemm_bf16_256x256<EPI>, dim3(nwg), dim3(NTHREADS), 0, st, a);

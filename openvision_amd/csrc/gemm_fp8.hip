@@ -393,16 +393,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_fp8_persist(const Fp8Args g)
     }
 }
 
-int num_cus_fp8() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0;
-        hipDeviceProp_t p;
-        n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0)
-                ? p.multiProcessorCount : 256;
-    }
-    return n;
-}
+int num_cus_fp8() { return ov_num_cus(); }
 
 template <int EPI, int MODE>
 int launch_fp8(const Fp8Args& a, hipStream_t st) {

@@ -18,7 +18,7 @@ struct LossArgs {
     float* part;            // [2][nsplit][bpad][2]  (max, sumexp) in natural-log units
     float* diag;            // [2][bpad]
     int b, N, E, bpad, nsplit, tiles_per_split, ntiles, label_offset;
-    float scale;
+    const float* scale;     // device scalar: the logit multiplier exp(logit_scale) (ABI 2: never crosses the host)
 };
 
 __global__ __launch_bounds__(256) void clip_logits_partial(const LossArgs a) {
@@ -32,6 +32,7 @@ __global__ __launch_bounds__(256) void clip_logits_partial(const LossArgs a) {
     const int rowc = row < a.b ? row : a.b - 1;
     const float* xp = X + (int64_t)rowc * a.E + 4 * half;
     const int label = row + a.label_offset;
+    const float scale = *a.scale;
 
     float m = -INFINITY, s = 0.f;
     const int t0 = split * a.tiles_per_split;
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(256) void clip_logits_partial(const LossArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int g = t * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
-            float v = acc[i] * a.scale;
+            float v = acc[i] * scale;
             if (g == label && row < a.b) a.diag[dir * a.bpad + row] = v;
             if (g >= a.N) v = -INFINITY;
             acc[i] = v;
@@ -128,7 +129,8 @@ __global__ __launch_bounds__(256) void clip_loss_finalize(const float* __restric
 // out[i, j] = scale * <X[i, :], Y[j, :]>  (CLIP.get_logits, model.py:286-293; fp32-exact MFMA). One wave per 32x32 tile.
 __global__ __launch_bounds__(64) void logits_kernel(const float* __restrict__ X, const float* __restrict__ Y,
                                                     float* __restrict__ out, int64_t ldo, int n1, int n2, int E,
-                                                    float scale) {
+                                                    float scale, const float* __restrict__ scale_dev) {
+    if (scale_dev) scale *= *scale_dev;
     const int lane = threadIdx.x & 63;
     const int j = lane & 31, half = lane >> 5;
     const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
@@ -175,7 +177,9 @@ struct LossBwdArgs {
     float* out[2];          // [no, E]
     float* dsc_part;        // [2][nrt]  (MODE_B = false only)
     int no, ni, E, label_offset, nrt;
-    float scale, coef;
+    const float* scale;     // device scalars (ABI 2): logit multiplier, upstream gradient of the loss (NULL = 1)
+    const float* grad;
+    float inv2b;
 };
 
 template <bool MODE_B>
@@ -195,6 +199,8 @@ __global__ __launch_bounds__(256) void clip_loss_bwd(const LossBwdArgs a) {
     const int oc = o < a.no ? o : a.no - 1;
     const float* xop = XO + (int64_t)oc * E + 4 * half;
     const float lse_o = MODE_B ? 0.f : LSE[oc];
+    const float scale = *a.scale;
+    const float coef = (a.grad ? *a.grad : 1.f) * a.inv2b * scale;
 
     f32x16_t acc_o[BWD_MAXT];
 #pragma unroll
@@ -236,7 +242,7 @@ __global__ __launch_bounds__(256) void clip_loss_bwd(const LossBwdArgs a) {
             const bool valid = o < a.no && g < a.ni;
             const float lse_v = MODE_B ? LSE[g < a.ni ? g : a.ni - 1] : lse_o;
             const bool hit = MODE_B ? (o == g + a.label_offset) : (g == o + a.label_offset);
-            const float pv = valid ? __expf(sdot * a.scale - lse_v) - (hit ? 1.f : 0.f) : 0.f;
+            const float pv = valid ? __expf(sdot * scale - lse_v) - (hit ? 1.f : 0.f) : 0.f;
             p[i] = pv;
             dsc = fmaf(pv, sdot, dsc);
         }
@@ -263,7 +269,7 @@ __global__ __launch_bounds__(256) void clip_loss_bwd(const LossBwdArgs a) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int row = rt * 32 + (i & 3) + 8 * (i >> 2) + 4 * half;
-                if (row < a.no) OUT[(int64_t)row * E + e] = acc_o[n][i] * a.coef;
+                if (row < a.no) OUT[(int64_t)row * E + e] = acc_o[n][i] * coef;
             }
         }
     }
@@ -273,11 +279,12 @@ __global__ __launch_bounds__(256) void clip_loss_bwd(const LossBwdArgs a) {
     }
 }
 
-__global__ __launch_bounds__(64) void clip_loss_bwd_scale(const float* __restrict__ part, int n, float coef, float* __restrict__ d_scale) {
+__global__ __launch_bounds__(64) void clip_loss_bwd_scale(const float* __restrict__ part, int n, float inv2b,
+                                                          const float* __restrict__ grad, float* __restrict__ d_scale) {
     float v = 0.f;
     for (int i = threadIdx.x; i < n; i += 64) v += part[i];
     v = wave_sum(v);
-    if (threadIdx.x == 0) d_scale[0] = v * coef;
+    if (threadIdx.x == 0) d_scale[0] = v * inv2b * (grad ? *grad : 1.f);
 }
 
 struct Plan { int bpad, nrt, ntiles, nsplit, tps; };
@@ -306,9 +313,9 @@ extern "C" size_t ov_clip_loss_workspace_bytes(int b, int N) {
 }
 
 extern "C" int ov_clip_loss(const float* img, const float* txt, const float* all_img, const float* all_txt, int b,
-                            int N, int E, float logit_scale, int label_offset, float* loss_out, float* lse_out,
+                            int N, int E, const float* logit_scale, int label_offset, float* loss_out, float* lse_out,
                             void* workspace, size_t workspace_bytes, ov_stream_t stream) {
-    if (!img || !txt || !all_img || !all_txt || !loss_out || !workspace) return OV_ERR_INVALID;
+    if (!img || !txt || !all_img || !all_txt || !loss_out || !workspace || !logit_scale) return OV_ERR_INVALID;
     if (b <= 0 || N < b || E <= 0 || label_offset < 0 || label_offset + b > N) return OV_ERR_INVALID;
     if (E % 8) return OV_ERR_UNSUPPORTED;
     if (((uintptr_t)img | (uintptr_t)txt | (uintptr_t)all_img | (uintptr_t)all_txt | (uintptr_t)workspace) & 15)
@@ -337,18 +344,18 @@ extern "C" size_t ov_clip_loss_backward_workspace_bytes(int b, int N) {
 }
 
 extern "C" int ov_clip_loss_backward(const float* img, const float* txt, const float* all_img, const float* all_txt, int b, int N,
-                                     int E, float logit_scale, int label_offset, const float* lse_terms, float grad_loss,
-                                     float* d_img, float* d_txt, float* d_all_img, float* d_all_txt, float* d_scale,
-                                     void* workspace, size_t workspace_bytes, ov_stream_t stream) {
-    if (!img || !txt || !all_img || !all_txt || !lse_terms || !d_img || !d_txt || !workspace) return OV_ERR_INVALID;
+                                     int E, const float* logit_scale, int label_offset, const float* lse_terms,
+                                     const float* grad_loss, float* d_img, float* d_txt, float* d_all_img, float* d_all_txt,
+                                     float* d_scale, void* workspace, size_t workspace_bytes, ov_stream_t stream) {
+    if (!img || !txt || !all_img || !all_txt || !lse_terms || !d_img || !d_txt || !workspace || !logit_scale) return OV_ERR_INVALID;
     if (b <= 0 || N < b || E <= 0 || label_offset < 0 || label_offset + b > N) return OV_ERR_INVALID;
     if (E % 32 || E > 4 * BWD_MAXT * 32) return OV_ERR_UNSUPPORTED;
     if (((uintptr_t)img | (uintptr_t)txt | (uintptr_t)all_img | (uintptr_t)all_txt | (uintptr_t)workspace) & 15) return OV_ERR_INVALID;
     if (workspace_bytes < ov_clip_loss_backward_workspace_bytes(b, N)) return OV_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    const float inv2b = grad_loss / (2.0f * (float)b);
+    const float inv2b = 1.0f / (2.0f * (float)b);
     LossBwdArgs a;
-    a.E = E; a.label_offset = label_offset; a.scale = logit_scale; a.coef = inv2b * logit_scale;
+    a.E = E; a.label_offset = label_offset; a.scale = logit_scale; a.grad = grad_loss; a.inv2b = inv2b;
     a.lse[0] = lse_terms; a.lse[1] = lse_terms + (size_t)2 * b;
     a.dsc_part = (float*)workspace;
     // local side: d img = c * P_i . all_txt, d txt = c * P_t . all_img
@@ -358,7 +365,7 @@ extern "C" int ov_clip_loss_backward(const float* img, const float* txt, const f
     hipLaunchKernelGGL(clip_loss_bwd<false>, dim3((unsigned)a.nrt, 2), dim3(256), 0, st, a);
     OV_LAUNCH_CHECK();
     if (d_scale) {
-        hipLaunchKernelGGL(clip_loss_bwd_scale, dim3(1), dim3(64), 0, st, a.dsc_part, 2 * a.nrt, inv2b, d_scale);
+        hipLaunchKernelGGL(clip_loss_bwd_scale, dim3(1), dim3(64), 0, st, a.dsc_part, 2 * a.nrt, inv2b, grad_loss, d_scale);
         OV_LAUNCH_CHECK();
     }
     if (d_all_img || d_all_txt) {
@@ -373,12 +380,12 @@ extern "C" int ov_clip_loss_backward(const float* img, const float* txt, const f
 }
 
 extern "C" int ov_logits(const float* X, const float* Y, float* out, int64_t ldo, int n1, int n2, int E, float scale,
-                         ov_stream_t stream) {
+                         const float* scale_dev, ov_stream_t stream) {
     if (!X || !Y || !out || n1 <= 0 || n2 <= 0 || E <= 0 || ldo < n2) return OV_ERR_INVALID;
     if (E % 8) return OV_ERR_UNSUPPORTED;
     if (((uintptr_t)X | (uintptr_t)Y) & 15) return OV_ERR_INVALID;
     hipLaunchKernelGGL(logits_kernel, dim3((unsigned)((n2 + 31) / 32), (unsigned)((n1 + 31) / 32)), dim3(64), 0,
-                       (hipStream_t)stream, X, Y, out, ldo, n1, n2, E, scale);
+                       (hipStream_t)stream, X, Y, out, ldo, n1, n2, E, scale, scale_dev);
     OV_LAUNCH_CHECK();
     return OV_OK;
 }

@@ -16,7 +16,18 @@
 #include <mutex>
 #include <stdlib.h>
 
+// Side stream for the "tail" images of a batch (tile-quantisation fix, see ov_tower_forward): owned by the tower, created on the
+// device that is current at the first forward that needs it; a forward on another device does not split.
+struct TailCtx {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    int state = 0;                         // 0 = not created, 1 = ok, -1 = unavailable
+    int device = -1;
+    std::mutex mu;                         // held from fork to join: two host threads on one tower must not interleave them
+};
+
 struct ov_tower {
+    mutable TailCtx tail;
     ov_tower_cfg cfg;
     ov_block_weights* blocks;
     unsigned char* set;
@@ -32,6 +43,7 @@ struct ProfRec { int cls; hipEvent_t e0, e1; int64_t rows; };
 struct Profiler {
     std::mutex mu;
     unsigned mask = 0;
+    int device = -1;                   // the device the event pool belongs to: launches on other devices are not recorded
     std::vector<hipEvent_t> pool;      // unused events
     std::vector<ProfRec> recs;
 } g_prof;
@@ -45,7 +57,7 @@ struct ProfScope {
     ProfScope(int c, ov_stream_t s, int64_t r) : st((hipStream_t)s), cls(c), rows(r) {
         if (!(g_prof.mask & (1u << c))) return;
         std::lock_guard<std::mutex> lk(g_prof.mu);
-        if (g_prof.pool.size() < 2) return;
+        if (g_prof.pool.size() < 2 || g_prof.device != ov_current_device()) return;
         e0 = g_prof.pool.back(); g_prof.pool.pop_back();
         e1 = g_prof.pool.back(); g_prof.pool.pop_back();
         on = true;
@@ -129,6 +141,12 @@ extern "C" int ov_profile_enable(unsigned class_mask, int max_records) {
     g_prof.recs.clear();
     g_prof.mask = class_mask;
     if (max_records < 0) return OV_ERR_INVALID;
+    const int dev = ov_current_device();
+    if (g_prof.device != dev) {                       // events are per device: a pool made elsewhere is dropped
+        for (hipEvent_t e : g_prof.pool) (void)hipEventDestroy(e);
+        g_prof.pool.clear();
+        g_prof.device = dev;
+    }
     while ((int)g_prof.pool.size() < 2 * max_records) {
         hipEvent_t e;
         hipError_t err = hipEventCreate(&e);
@@ -178,6 +196,11 @@ extern "C" ov_tower* ov_tower_create(const ov_tower_cfg* cfg) {
 
 extern "C" void ov_tower_destroy(ov_tower* t) {
     if (!t) return;
+    if (t->tail.state == 1) {
+        (void)hipEventDestroy(t->tail.fork);
+        (void)hipEventDestroy(t->tail.join);
+        (void)hipStreamDestroy(t->tail.stream);
+    }
     delete[] t->blocks;
     delete[] t->set;
     delete[] t->fp8;
@@ -275,28 +298,22 @@ int run_block(const ov_tower_cfg& c, const ov_block_weights& w, ov_bf16* x, ov_b
     return OV_OK;
 }
 
-// Side stream for the "tail" images of a batch (tile-quantisation fix, see ov_tower_forward).
-struct TailCtx {
-    hipStream_t stream = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
-    int state = 0;                         // 0 = not created, 1 = ok, -1 = unavailable
-};
-TailCtx g_tail;
-std::mutex g_tail_mu;
-
-TailCtx* tail_ctx() {
-    std::lock_guard<std::mutex> lk(g_tail_mu);
-    if (g_tail.state == 0) {
+// The tower's tail context if it is usable on the CURRENT device (created on first use), else nullptr (= do not split).
+TailCtx* tail_ctx(const ov_tower* t) {
+    TailCtx& tc = t->tail;
+    std::lock_guard<std::mutex> lk(tc.mu);
+    if (tc.state == 0) {
         const char* e = getenv("OVHIP_NO_TAIL_SPLIT");
-        if (e && e[0] == '1') { g_tail.state = -1; return nullptr; }
-        if (hipStreamCreateWithFlags(&g_tail.stream, hipStreamNonBlocking) == hipSuccess &&
-            hipEventCreateWithFlags(&g_tail.fork, hipEventDisableTiming) == hipSuccess &&
-            hipEventCreateWithFlags(&g_tail.join, hipEventDisableTiming) == hipSuccess)
-            g_tail.state = 1;
+        if (e && e[0] == '1') { tc.state = -1; return nullptr; }
+        tc.device = ov_current_device();
+        if (hipStreamCreateWithFlags(&tc.stream, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreateWithFlags(&tc.fork, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&tc.join, hipEventDisableTiming) == hipSuccess)
+            tc.state = 1;
         else
-            g_tail.state = -1;
+            tc.state = -1;
     }
-    return g_tail.state == 1 ? &g_tail : nullptr;
+    return tc.state == 1 && tc.device == ov_current_device() ? &tc : nullptr;
 }
 
 // Images to peel off so that the main part's 256-row tile count is a multiple of 64 (x 4 column tiles = whole rounds of
@@ -383,47 +400,49 @@ extern "C" int ov_tower_forward(const ov_tower* t, ov_bf16* x, int B, int L, voi
         if (!t->set[i]) return OV_ERR_INVALID;
 
     int nt = tail_images(B, L);
-    TailCtx* tc = nt > 0 ? tail_ctx() : nullptr;
+    TailCtx* tc = nt > 0 ? tail_ctx(t) : nullptr;
     if (!tc) nt = 0;
     const int Bm = B - nt;
     hipStream_t main_st = (hipStream_t)stream;
+    // fork .. join under the tower's mutex: the events are this tower's own, a second host thread enqueues after the join
+    std::unique_lock<std::mutex> tail_lock;
     if (nt > 0) {
+        tail_lock = std::unique_lock<std::mutex>(tc->mu);
         hipError_t e = hipEventRecord(tc->fork, main_st);
         if (e == hipSuccess) e = hipStreamWaitEvent(tc->stream, tc->fork, 0);
         if (e != hipSuccess) return OV_ERR_HIP - (int)e;
     }
     const int64_t off = (int64_t)Bm * L;
     const bool fp8 = tower_fp8(t);
-    if (fp8 && t->h_amax && t->h_mode == 2) {          // delayed scaling: last forward's maxima become this forward's scales
-        int rc = ov_amax_roll(t->h_amax, t->h_amax + 2 * c.layers, 2 * c.layers, stream);
-        if (rc) return rc;
-    }
+    int rc = OV_OK;
+    if (fp8 && t->h_amax && t->h_mode == 2)            // delayed scaling: last forward's maxima become this forward's scales
+        rc = ov_amax_roll(t->h_amax, t->h_amax + 2 * c.layers, 2 * c.layers, stream);
     const int qw = D > c.mlp_pad ? D : c.mlp_pad;                 // row pitch reserved per token in the fp8 activation buffer
     unsigned char* q8 = (unsigned char*)stats + align_up((size_t)M * 8, 256);
     float* qs = (float*)(q8 + align_up((size_t)M * qw, 256));
-    for (int i = 0; i < c.layers; ++i) {
+    for (int i = 0; i < c.layers && rc == OV_OK; ++i) {
         float* ha = t->h_amax ? t->h_amax + i : nullptr;
         float* aa = t->h_amax ? t->h_amax + c.layers + i : nullptr;
         float* hn = t->h_amax ? t->h_amax + 2 * c.layers + i : nullptr;
         float* an = t->h_amax ? t->h_amax + 3 * c.layers + i : nullptr;
         const int hm = t->h_amax ? t->h_mode : 0;
-        int rc = fp8 ? run_block_fp8(c, t->blocks[i], t->fp8[i], x, h, big, q8, qs, ha, aa, hn, an, hm, Bm, L, stream, true)
-                     : run_block(c, t->blocks[i], x, h, big, stats, Bm, L, stream, true);
-        if (rc) return rc;
-        if (nt > 0) {
+        rc = fp8 ? run_block_fp8(c, t->blocks[i], t->fp8[i], x, h, big, q8, qs, ha, aa, hn, an, hm, Bm, L, stream, true)
+                 : run_block(c, t->blocks[i], x, h, big, stats, Bm, L, stream, true);
+        if (rc == OV_OK && nt > 0) {
             rc = fp8 ? run_block_fp8(c, t->blocks[i], t->fp8[i], x + off * D, h + off * D, big + off * ldb, q8 + off * qw, qs + off,
                                      ha, aa, hn, an, hm, nt, L, (ov_stream_t)tc->stream, false)
                      : run_block(c, t->blocks[i], x + off * D, h + off * D, big + off * ldb, stats + 2 * off, nt, L,
                                  (ov_stream_t)tc->stream, false);
-            if (rc) return rc;
         }
     }
     if (nt > 0) {
+        // always join, also after an error between fork and here: whatever the side stream got stays ordered before the
+        // caller's next work on `stream` (and before the workspace is reused)
         hipError_t e = hipEventRecord(tc->join, tc->stream);
         if (e == hipSuccess) e = hipStreamWaitEvent(main_st, tc->join, 0);
-        if (e != hipSuccess) return OV_ERR_HIP - (int)e;
+        if (e != hipSuccess && rc == OV_OK) rc = OV_ERR_HIP - (int)e;
     }
-    return OV_OK;
+    return rc;
 }
 
 // ---- training-side entry points: keep every block's input, run the blocks' backward in reverse -------------

@@ -45,8 +45,9 @@ class ClipLoss(nn.Module):
     """Same constructor and call signature as the reference (loss.py:68-83,120-131)."""
 
     def __init__(self, local_loss: bool = False, gather_with_grad: bool = False, cache_labels: bool = False,
-                 rank: int = 0, world_size: int = 1, use_horovod: bool = False):
+                 rank: int = 0, world_size: int = 1, use_horovod: bool = False, group=None):
         super().__init__()
+        self.group = group          # process group of the gather / reduce-scatter (None = the default group, as the reference)
         if use_horovod:
             raise NotImplementedError("horovod transport is not supported; use torch.distributed (RCCL)")
         self.local_loss, self.gather_with_grad, self.cache_labels = local_loss, gather_with_grad, cache_labels
@@ -54,7 +55,17 @@ class ClipLoss(nn.Module):
         self._ws: Optional[torch.Tensor] = None
         self.last_terms: Optional[torch.Tensor] = None     # [4, b]: lse_img, diag_img, lse_txt, diag_txt
 
-    def _loss_strips(self, img, txt, all_img, all_txt, scale: float, label_offset: int) -> torch.Tensor:
+    @staticmethod
+    def _device_scale(logit_scale, device) -> torch.Tensor:
+        """The logit multiplier as a 1-element fp32 DEVICE tensor.  It never visits the host (ovhip.h ABI 2): `float(logit_scale)`
+        would drain the stream after both towers before the loss could be enqueued."""
+        if isinstance(logit_scale, torch.Tensor):
+            if not logit_scale.is_cuda:
+                return logit_scale.detach().float().reshape(1).to(device, non_blocking=True)
+            return logit_scale.detach().float().reshape(1)
+        return torch.full((1,), float(logit_scale), dtype=torch.float32, device=device)
+
+    def _loss_strips(self, img, txt, all_img, all_txt, scale: torch.Tensor, label_offset: int) -> torch.Tensor:
         if not img.is_cuda:
             raise _lib.OvhipError("ClipLoss: features must live on an MI355X device (no CPU fallback)")
         lib = _lib.load()
@@ -67,7 +78,7 @@ class ClipLoss(nn.Module):
             self._ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=img.device)
         out = torch.empty(1, dtype=torch.float32, device=img.device)
         terms = torch.empty(4, b, dtype=torch.float32, device=img.device)
-        check(lib.ov_clip_loss(ptr(img), ptr(txt), ptr(all_img), ptr(all_txt), b, n, e, float(scale), int(label_offset),
+        check(lib.ov_clip_loss(ptr(img), ptr(txt), ptr(all_img), ptr(all_txt), b, n, e, ptr(scale), int(label_offset),
                                ptr(out), ptr(terms), ptr(self._ws), nbytes, stream_ptr()), "ov_clip_loss")
         self.last_terms = terms
         return out[0]
@@ -80,10 +91,12 @@ class ClipLoss(nn.Module):
                 logit_scale = torch.tensor(float(logit_scale), device=image_features.device)
             loss = _ClipLossFn.apply(self, image_features, text_features, logit_scale)
             return {"contrastive_loss": loss} if output_dict else loss
-        scale = float(logit_scale.detach()) if isinstance(logit_scale, torch.Tensor) else float(logit_scale)
+        if not image_features.is_cuda:
+            raise _lib.OvhipError("ClipLoss: features must live on an MI355X device (no CPU fallback)")
+        scale = self._device_scale(logit_scale, image_features.device)
         if self.world_size > 1:
             all_img, all_txt = gather_features(image_features, text_features, self.local_loss, self.gather_with_grad,
-                                               self.rank, self.world_size, self.use_horovod)
+                                               self.rank, self.world_size, self.use_horovod, self.group)
             if self.local_loss:
                 loss = self._loss_strips(image_features, text_features, all_img, all_txt, scale,
                                          image_features.shape[0] * self.rank)
@@ -116,24 +129,24 @@ class _ClipLossFn(torch.autograd.Function):
         img, txt = image_features.detach().float().contiguous(), text_features.detach().float().contiguous()
         b = img.shape[0]
         if ws > 1:
-            all_img, all_txt = gather_features(img, txt, mod.local_loss, mod.gather_with_grad, rank, ws, mod.use_horovod)
+            all_img, all_txt = gather_features(img, txt, mod.local_loss, mod.gather_with_grad, rank, ws, mod.use_horovod, mod.group)
         else:
             all_img, all_txt = img, txt
         if ws > 1 and not mod.local_loss:
             x_img, x_txt, off = all_img, all_txt, 0          # every rank evaluates the global loss (loss.py:111-113)
         else:
             x_img, x_txt, off = img, txt, b * rank
-        scale = float(logit_scale.detach())
+        scale = mod._device_scale(logit_scale, img.device)
         loss = mod._loss_strips(x_img, x_txt, all_img, all_txt, scale, off)
-        ctx.mod, ctx.scale, ctx.off, ctx.b = mod, scale, off, b
+        ctx.mod, ctx.off, ctx.b = mod, off, b
         ctx.in_dtypes = (image_features.dtype, text_features.dtype, logit_scale.dtype)
-        ctx.save_for_backward(x_img, x_txt, all_img, all_txt, mod.last_terms)
+        ctx.save_for_backward(x_img, x_txt, all_img, all_txt, mod.last_terms, scale)
         return loss
 
     @staticmethod
     def backward(ctx, grad_out):
         mod: "ClipLoss" = ctx.mod
-        x_img, x_txt, all_img, all_txt, terms = ctx.saved_tensors
+        x_img, x_txt, all_img, all_txt, terms, scale = ctx.saved_tensors
         lib = _lib.load()
         ws, rank, b = mod.world_size, mod.rank, ctx.b
         bx, e = x_img.shape
@@ -144,10 +157,11 @@ class _ClipLossFn(torch.autograd.Function):
         d_img, d_txt = torch.empty_like(x_img), torch.empty_like(x_txt)
         d_all = torch.empty(2, n, e, dtype=torch.float32, device=x_img.device) if gathered_grad else None
         d_scale = torch.empty(1, dtype=torch.float32, device=x_img.device)
+        grad = grad_out.detach().float().reshape(1).contiguous()        # device scalar: no host round trip
         nbytes = lib.ov_clip_loss_backward_workspace_bytes(bx, n)
         wsb = torch.empty(nbytes + 256, dtype=torch.uint8, device=x_img.device)
-        check(lib.ov_clip_loss_backward(ptr(x_img), ptr(x_txt), ptr(all_img), ptr(all_txt), bx, n, e, ctx.scale, ctx.off, ptr(terms),
-                                        float(grad_out), ptr(d_img), ptr(d_txt), ptr(d_all[0]) if gathered_grad else None,
+        check(lib.ov_clip_loss_backward(ptr(x_img), ptr(x_txt), ptr(all_img), ptr(all_txt), bx, n, e, ptr(scale), ctx.off, ptr(terms),
+                                        ptr(grad), ptr(d_img), ptr(d_txt), ptr(d_all[0]) if gathered_grad else None,
                                         ptr(d_all[1]) if gathered_grad else None, ptr(d_scale), ptr(wsb), nbytes, stream_ptr()),
               "ov_clip_loss_backward")
         if ws == 1:
@@ -155,11 +169,11 @@ class _ClipLossFn(torch.autograd.Function):
         elif mod.local_loss:
             g_img, g_txt = d_img, d_txt
             if mod.gather_with_grad:
-                own = _sum_over_ranks_own_chunk(torch.cat([d_all[0], d_all[1]], dim=1), b, rank)
+                own = _sum_over_ranks_own_chunk(torch.cat([d_all[0], d_all[1]], dim=1), b, rank, mod.group)
                 g_img, g_txt = g_img + own[:, :e], g_txt + own[:, e:]
         else:
             tot = torch.cat([d_img + d_all[0], d_txt + d_all[1]], dim=1)          # [N, 2E]: both sides are the global set
-            own = _sum_over_ranks_own_chunk(tot, b, rank) if mod.gather_with_grad else tot[rank * b:(rank + 1) * b]
+            own = _sum_over_ranks_own_chunk(tot, b, rank, mod.group) if mod.gather_with_grad else tot[rank * b:(rank + 1) * b]
             g_img, g_txt = own[:, :e], own[:, e:]
         dt_i, dt_t, dt_s = ctx.in_dtypes
         return None, g_img.to(dt_i), g_txt.to(dt_t), d_scale[0].to(dt_s)

@@ -66,20 +66,30 @@ class _Workspace:
         return self.buf
 
 
+_PACK_EPOCH = [0]        # bumped by invalidate_packed(): every _Packed signature carries it
+
+
 class _Packed:
-    """Cache of packed device tensors keyed by the source parameters' (data_ptr, version)."""
+    """Cache of packed device tensors keyed by the source parameters' (data_ptr, version).  Writes that bypass autograd's
+    version counter (``p.data.copy_()``, ``p.data.mul_()``, EMA / weight surgery through ``.data``) are NOT seen: call
+    ``invalidate_packed()`` (or ``CLIP.invalidate_packed()``) after them.  ``load_state_dict`` does it by itself."""
 
     def __init__(self):
         self.sig = None
         self.val = None
 
     def get(self, params, builder, extra=None):
-        sig = (extra,) + tuple((p.data_ptr(), p._version, p.dtype, p.device) for p in params)
+        sig = (extra, _PACK_EPOCH[0]) + tuple((p.data_ptr(), p._version, p.dtype, p.device) for p in params)
         if sig != self.sig:
             with torch.no_grad():
                 self.val = builder()
             self.sig = sig
         return self.val
+
+
+def invalidate_packed() -> None:
+    """Drop every packed / folded / quantised device copy of every model in this process; they are rebuilt on next use."""
+    _PACK_EPOCH[0] += 1
 
 
 def _pack_matrix(w: torch.Tensor, n_pad: int, k_pad: int) -> torch.Tensor:
@@ -564,7 +574,11 @@ class VisionTransformer(nn.Module):
             img = x.detach().contiguous()
             tok = self._embed_tokens(img if img.dtype in (torch.float32, torch.bfloat16) else img.float())
             tok = self.transformer(self.ln_pre(tok))
-            return self._head_forward(tok, False), tok[:, 1:].to(x.dtype)
+            pooled = self._head_forward(tok, False)
+            tokens = tok[:, 1:]
+            if not self.final_ln_after_pool:        # transformer.py:641-645: ln_post runs on all tokens BEFORE pooling
+                tokens = self.ln_post(tokens.contiguous())
+            return pooled, tokens.to(x.dtype)
         return self._encode(x, False)
 
 
@@ -679,7 +693,7 @@ class CLIP(nn.Module):
         """model.py:286-293."""
         i = self.encode_image(image, normalize=True)
         t = self.encode_text(text, normalize=True)
-        li = logits(i, t, float(self.logit_scale.detach().exp()))
+        li = logits(i, t, self.logit_scale.detach().exp())       # the scale stays on the device (model.py:288)
         return li, li.T
 
     def forward(self, image: Optional[torch.Tensor] = None, text: Optional[torch.Tensor] = None):
@@ -705,6 +719,16 @@ class CLIP(nn.Module):
             return {"image_features": image_features, "text_features": text_features, "logit_scale": scale}
         return image_features, text_features, scale
 
+    def invalidate_packed(self) -> None:
+        """Forget the bf16 / fp8 packed copies, folded LayerNorm weights and tower handles (see ``_Packed``): required after
+        in-place parameter writes through ``.data``, which leave ``_version`` unchanged."""
+        invalidate_packed()
+
+    def load_state_dict(self, *a, **k):
+        out = super().load_state_dict(*a, **k)
+        invalidate_packed()          # copy_ under no_grad bumps _version today; do not depend on it
+        return out
+
     def lock_image_tower(self, *a, **k):
         raise NotImplementedError("not provided: the training path (openvision_amd.training) differentiates every parameter")
 
@@ -713,13 +737,18 @@ class CLIP(nn.Module):
             raise NotImplementedError("not needed: openvision_amd.training keeps per-layer activations and recomputes the rest itself")
 
 
-def logits(a: torch.Tensor, b: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
-    """scale * a @ b.T for fp32 embeddings on device (exact-fp32 MFMA kernel)."""
+def logits(a: torch.Tensor, b: torch.Tensor, scale=1.0) -> torch.Tensor:
+    """scale * a @ b.T for fp32 embeddings on device (exact-fp32 MFMA kernel).  `scale`: a float, or a 0-d / 1-element tensor that is
+    read on the device (no host synchronisation)."""
     _require_cuda(a, "logits")
+    sdev = None
+    if isinstance(scale, torch.Tensor):
+        sdev = scale.detach().float().reshape(1).to(a.device)
+        scale = 1.0
     a32, b32 = a.detach().float().contiguous(), b.detach().float().contiguous()
     out = torch.empty(a32.shape[0], b32.shape[0], dtype=torch.float32, device=a.device)
     check(_lib.load().ov_logits(ptr(a32), ptr(b32), ptr(out), out.shape[1], a32.shape[0], b32.shape[0], a32.shape[1],
-                                float(scale), stream_ptr()), "ov_logits")
+                                float(scale), ptr(sdev), stream_ptr()), "ov_logits")
     return out
 
 

@@ -8,8 +8,13 @@ the per-image sorted cosine / probability table (:167-195) and the per-text best
 ``openvision_amd.tokenizer`` (the reference's WordPiece tokenizer restated; ``<DIR>/vocab.txt`` if present, else the packaged
 vocabulary) or given as an int64 ``[n, context_length]`` ``.npy`` of token ids; images are decoded on the host and resized /
 normalised on the device (``openvision_amd.preprocess``).
-``DIR`` holds ``open_clip_config.json`` and either ``open_clip_pytorch_model.bin`` (loaded with
-``torch.load(weights_only=True)``) or, with ``--synthetic``, formula weights.
+``DIR`` holds ``open_clip_config.json`` and the weights (``open_clip_pytorch_model.bin`` read with
+``torch.load(weights_only=True)``, or safetensors; ``openvision_amd.checkpoint``) or, with ``--synthetic``, formula weights.
+
+Token framing: PARITY UNPINNED against the script.  The script tokenises with ``HFTokenizer(cfg.text_cfg.hf_tokenizer_name)``
+(``ov-zero-shot-test.py:81``: ``AutoTokenizer`` framing taken from a hub config that is not on disk: [CLS] ... [SEP] then zero
+padding).  ``--prompts`` here uses the TRAINING framing of ``CLIPS_Tokenizer`` (``open_clip/tokenizer.py:522-594``: bos 1 ... eos 2,
+zero padding, class token 101 last), which is what the text tower's last-token pooling was trained on.
 """
 from __future__ import annotations
 
@@ -53,8 +58,7 @@ def zero_shot_table(model, images: torch.Tensor, tokens: torch.Tensor):
     tf = model.encode_text(tokens, normalize=True)
     rows = [logits(model.encode_image(images[i:i + 1], normalize=True), tf)[0] for i in range(images.shape[0])]
     cos = torch.stack(rows)
-    scale = float(model.logit_scale.detach().exp())
-    probs = torch.softmax(cos * scale, dim=-1)       # [n_img, n_txt] softmax: plumbing on a 5x9 table
+    probs = torch.softmax(cos * model.logit_scale.detach().exp(), dim=-1)       # [n_img, n_txt] softmax: plumbing on a 5x9 table
     return cos, probs, cos.argsort(dim=-1, descending=True)
 
 
@@ -69,11 +73,11 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     a = ap.parse_args(argv)
     model_cfg, pp = ovcfg.load_config_dir(a.use_model)
     if a.synthetic:
-        sd = synth.make_state_dict(model_cfg)
+        model = create_model({k: v for k, v in model_cfg.items() if k in ("embed_dim", "vision_cfg", "text_cfg")},
+                             device="cuda:0", state_dict=synth.make_state_dict(model_cfg))
     else:
-        sd = torch.load(os.path.join(a.use_model, "open_clip_pytorch_model.bin"), map_location="cpu", weights_only=True)
-    model = create_model({k: v for k, v in model_cfg.items() if k in ("embed_dim", "vision_cfg", "text_cfg")},
-                         device="cuda:0", state_dict=sd)
+        from .checkpoint import from_pretrained
+        model, pp = from_pretrained(a.use_model, device="cuda:0")     # .bin (weights_only) or safetensors, wrappers unwrapped
     print(describe(model))
     names, imgs = load_images(a.image_dir, model_cfg["vision_cfg"]["image_size"], pp["mean"], pp["std"])
     if bool(a.tokens) == bool(a.prompts):

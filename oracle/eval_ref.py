@@ -3,8 +3,11 @@
   zero_shot_classifier   src/convert_upload/open_clip/zero_shot_classifier.py:51-57
   count_correct          src/evaluators/proj/image_text/discriminative_classifier.py:305-323
   retrieval recall@k     src/evaluators/proj/image_text/image_text_retrieval.py:24-87
-PARITY PINNING: these are restated verbatim in numpy (argsort / any / mean on small integer arrays); the reference's own
-versions need jax/tfds to import, so they are pinned by construction against hand-checkable cases in tests/test_eval_oracle.py.
+PARITY PINNING: pinned for the retrieval recall@k and the zero-shot classifier weights -- tests/golden/make_golden.py (gen_eval)
+runs the reference's own image_text_retrieval.py (numpy-only, loaded from its file) and zero_shot_classifier.py (torch-only, via
+the bare open_clip package) and commits tests/golden/eval.npz; tests/test_eval_oracle.py checks these functions against it.
+count_correct stays pinned by hand-checkable cases only: discriminative_classifier.py imports jax / tfds at module level
+(parity unpinned for that function).  TEST INFRASTRUCTURE ONLY: nothing under openvision_amd/ imports this module.
 """
 import numpy as np
 

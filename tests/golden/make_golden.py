@@ -19,6 +19,7 @@ Files written (np.savez_compressed):
   *_sharp.npz             Ti/16, L/14, S/8 on the 'sharp' weights + structured images: separated embeddings, per-block slices
   large14_224.npz         L/14@224 + text-L, B=2: features (fp32 and the reference's bf16 mode), token slices
   small8_384.npz          S/8@384, B=1 (2305 tokens): features, token slices
+  eval.npz                recall@k from the reference's image_text_retrieval.py, classifier weights from its zero_shot_classifier.py
   cliploss_ws.npz         ClipLoss(local_loss=True) per-rank losses at world_size 2 and 8 over gloo
   opgrad.npz              autograd through the reference's LayerNorm / nn.Linear / nn.GELU for random upstream gradients
   blockgrad.npz           autograd through the reference ResidualAttentionBlock (Tiny block 0): d input + parameter gradients
@@ -512,6 +513,51 @@ def gen_tokenizer(ref_root, out):
     np.savez_compressed(out, texts=np.array(texts), ids=np.array(rows, dtype=np.int64))
 
 
+def gen_eval(ref_root, out):
+    """Evaluator arithmetic from the reference's own modules: recall@k of src/evaluators/proj/image_text/image_text_retrieval.py
+    (numpy-only, loaded from its file) on a seeded distance matrix without ties, and the classifier weights of
+    open_clip/zero_shot_classifier.py:21-68 (torch-only, through the bare open_clip package) driven by a table-lookup stand-in for
+    the model / tokenizer pair (encode_text = rows of a seeded, normalised embedding table; the arithmetic under test is the
+    reshape / mean / renormalise / transpose / batch-concatenate of :51-66)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "ref_image_text_retrieval", os.path.join(ref_root, "src/evaluators/proj/image_text/image_text_retrieval.py"))
+    itr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(itr)
+    g = np.random.default_rng(2024)
+    n_img, per = 48, 5
+    corr = np.repeat(np.arange(n_img), per)
+    zi = g.standard_normal((n_img, 64)).astype(np.float32)
+    zt = (zi[corr] * 0.22 + g.standard_normal((n_img * per, 64)).astype(np.float32)).astype(np.float32)
+    zi /= np.linalg.norm(zi, axis=1, keepdims=True)
+    zt /= np.linalg.norm(zt, axis=1, keepdims=True)
+    dist = (-(zi @ zt.T)).astype(np.float32)                    # retrieval.py:280-303 feeds -similarity
+    # no ties within a row or a column: both argsort orders are unambiguous
+    assert all(len(np.unique(r)) == r.size for r in dist) and all(len(np.unique(c)) == c.size for c in dist.T)
+    t2i = itr.text_to_image_retrieval_eval(dist, list(corr))
+    i2t = itr.image_to_text_retrieval_eval(dist, list(corr))
+    res = {"zimg": zi, "ztxt": zt, "dist": dist, "corr": corr.astype(np.int64),
+           "t2i": np.array([t2i[f"Recall@{k}"] for k in itr.RECALL_THRESHOLDS], dtype=np.float64),
+           "i2t": np.array([i2t[f"Recall@{k}"] for k in itr.RECALL_THRESHOLDS], dtype=np.float64),
+           "thresholds": np.array(itr.RECALL_THRESHOLDS)}
+    zsc = importlib.import_module("open_clip.zero_shot_classifier")
+    C_, T_, E_ = 23, 7, 64
+    table = torch.from_numpy(g.standard_normal((C_ * T_, E_)).astype(np.float32))
+
+    class Model:
+        def encode_text(self, ids, normalize=False):
+            x = table[ids]
+            return torch.nn.functional.normalize(x, dim=-1) if normalize else x
+
+    names = [str(c) for c in range(C_)]
+    templates = [(lambda c, t=t: f"{c}:{t}") for t in range(T_)]
+    tokenizer = lambda texts: torch.tensor([int(x.split(":")[0]) * T_ + int(x.split(":")[1]) for x in texts])
+    w = zsc.build_zero_shot_classifier(Model(), tokenizer, names, templates, num_classes_per_batch=10)
+    res.update(zs_text_norm=torch.nn.functional.normalize(table, dim=-1).numpy(), zs_weights=w.numpy(),
+               zs_classes=np.int64(C_), zs_templates=np.int64(T_))
+    np.savez_compressed(out, **res)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -526,6 +572,7 @@ def main():
         "testcat": lambda: gen_testcat(m, a.ref, os.path.join(HERE, "tiny16_160_testcat.npz")),
         "large": lambda: gen_large(m, lossmod, os.path.join(HERE, "large14_224.npz")),
         "sharp": lambda: gen_sharp(m, lossmod, HERE),
+        "eval": lambda: gen_eval(a.ref, os.path.join(HERE, "eval.npz")),
         "small": lambda: gen_small(m, os.path.join(HERE, "small8_384.npz")),
         "cliploss": lambda: gen_cliploss(lossmod, a.ref, os.path.join(HERE, "cliploss_ws.npz")),
         "preprocess": lambda: gen_preprocess(a.ref, os.path.join(HERE, "preprocess.npz")),

@@ -46,7 +46,9 @@ def clip_loss(img, txt, all_img, all_txt, scale, label_offset):
     ws = torch.empty(nb + 16, dtype=torch.uint8, device=img.device)
     out = torch.empty(1, dtype=torch.float32, device=img.device)
     terms = torch.empty(4, b, dtype=torch.float32, device=img.device)
-    check(lib.ov_clip_loss(ptr(img), ptr(txt), ptr(all_img), ptr(all_txt), b, n, e, float(scale), label_offset, ptr(out),
+    sc = (scale.detach().float().reshape(1) if isinstance(scale, torch.Tensor) and scale.is_cuda
+          else torch.full((1,), float(scale), dtype=torch.float32, device=img.device))
+    check(lib.ov_clip_loss(ptr(img), ptr(txt), ptr(all_img), ptr(all_txt), b, n, e, ptr(sc), label_offset, ptr(out),
                            ptr(terms), ptr(ws), nb, stream_ptr()))
     return out[0], terms
 
@@ -137,8 +139,10 @@ def clip_loss_backward(img, txt, all_img, all_txt, scale, label_offset, terms, g
     d_s = torch.empty(1, dtype=torch.float32, device=img.device)
     nb = lib.ov_clip_loss_backward_workspace_bytes(b, n)
     ws = torch.empty(nb + 256, dtype=torch.uint8, device=img.device)
-    check(lib.ov_clip_loss_backward(ptr(img), ptr(txt), ptr(all_img), ptr(all_txt), b, n, e, float(scale), label_offset, ptr(terms),
-                                    float(grad), ptr(d_img), ptr(d_txt), ptr(d_ai) if gathered else None,
+    sc = torch.full((1,), float(scale), dtype=torch.float32, device=img.device)
+    gr = torch.full((1,), float(grad), dtype=torch.float32, device=img.device)
+    check(lib.ov_clip_loss_backward(ptr(img), ptr(txt), ptr(all_img), ptr(all_txt), b, n, e, ptr(sc), label_offset, ptr(terms),
+                                    ptr(gr), ptr(d_img), ptr(d_txt), ptr(d_ai) if gathered else None,
                                     ptr(d_at) if gathered else None, ptr(d_s), ptr(ws), nb, stream_ptr()), "ov_clip_loss_backward")
     return d_img, d_txt, d_ai, d_at, d_s
 

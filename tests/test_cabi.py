@@ -26,7 +26,7 @@ def test_header_symbols_exported_and_bound():
 
 def test_library_loads_and_reports_missing_device_cleanly():
     lib = _lib.load()
-    assert lib.ov_abi_version() == 1
+    assert lib.ov_abi_version() == 2
     assert lib.ov_error_string(0) == b"ok"
     assert lib.ov_error_string(-2).startswith(b"shape")
     import torch
@@ -59,7 +59,7 @@ def test_argument_validation_of_the_widening_entry_points():
     assert lib.ov_gemm_fp8_static(None, 1024, None, 1024, None, None, None, None, None, 1024, None, None, 256, 256, 1024, 1, None, 0, None) == -1
     assert lib.ov_amax_roll(None, None, 4, None) == -1
     # loss backward: null pointers are rejected; the workspace holds one partial per 32-row tile and direction
-    assert lib.ov_clip_loss_backward(None, None, None, None, 16, 16, 192, 1.0, 0, None, 1.0, None, None, None, None, None, None, 0, None) == -1
+    assert lib.ov_clip_loss_backward(None, None, None, None, 16, 16, 192, None, 0, None, None, None, None, None, None, None, None, 0, None) == -1
     assert lib.ov_clip_loss_backward_workspace_bytes(256, 2048) >= 2 * 8 * 4
     # operator-level backward: nulls and unsupported shapes are status codes
     assert lib.ov_transpose_bf16(None, 8, 8, 8, None, 64, None) == -1

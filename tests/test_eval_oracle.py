@@ -37,6 +37,37 @@ def test_zero_shot_classifier_shapes_and_norm():
     np.testing.assert_allclose(np.linalg.norm(w, axis=0), 1.0, atol=1e-6)
 
 
+def test_retrieval_recall_pinned_to_reference():
+    """oracle.eval_ref vs tests/golden/eval.npz = outputs of the reference's image_text_retrieval.py:24-87 on the committed matrix."""
+    from conftest import golden
+    g = golden("eval.npz")
+    t = E.text_to_image_retrieval_eval(g["dist"], list(g["corr"]))
+    i = E.image_to_text_retrieval_eval(g["dist"], list(g["corr"]))
+    for n, k in enumerate(g["thresholds"]):
+        assert t[f"Recall@{k}"] == g["t2i"][n] and i[f"Recall@{k}"] == g["i2t"][n]
+    assert 0.2 < g["t2i"][0] < 0.6 < g["t2i"][2] < 1.0          # the fixture discriminates (not all-hit / all-miss)
+
+
+def test_zero_shot_classifier_pinned_to_reference():
+    """oracle.eval_ref.zero_shot_classifier vs the reference's build_zero_shot_classifier (zero_shot_classifier.py:21-68)."""
+    from conftest import golden
+    g = golden("eval.npz")
+    w = E.zero_shot_classifier(g["zs_text_norm"], int(g["zs_classes"]), int(g["zs_templates"]))
+    np.testing.assert_allclose(w, g["zs_weights"], atol=1e-6)
+
+
+def test_checkpoint_module_prefix_and_state_dict_wrapper(tmp_path):
+    """factory.py:134-147: {'state_dict': ...} wrappers and DDP 'module.' prefixes are removed before the strict load."""
+    cfg = preset("vit-tiny-patch16-160")
+    sd = synth.make_state_dict(cfg)
+    m = create_model(cfg, state_dict=sd)
+    ck.save_pretrained(m, cfg, str(tmp_path), safetensors=False)
+    torch.save({"epoch": 3, "state_dict": {"module." + k: v for k, v in sd.items()}}, tmp_path / ck.BIN_NAME)
+    m2, _ = ck.from_pretrained(str(tmp_path), device=None)
+    for k, v in sd.items():
+        assert torch.equal(m2.state_dict()[k], v), k
+
+
 def test_checkpoint_dir_roundtrip(tmp_path):
     cfg = preset("vit-tiny-patch16-160")
     sd = synth.make_state_dict(cfg)

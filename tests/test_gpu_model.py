@@ -331,6 +331,25 @@ def test_zero_shot_and_retrieval_evaluators(tiny):
     assert ev.topk(x, 2, largest=False)[1].tolist() == [[0, 3], [0, 1]]
 
 
+def test_evaluators_against_reference_fixture():
+    """The device evaluators (ov_logits + ov_topk + ov_class_mean_normalize) on the committed embeddings of tests/golden/eval.npz
+    against the outputs of the REFERENCE's image_text_retrieval.py:24-87 / zero_shot_classifier.py:21-68 (make_golden.py gen_eval)."""
+    from openvision_amd import evaluate as ev
+    from openvision_amd import _lib
+    from openvision_amd._lib import ptr, stream_ptr, check
+    g = golden("eval.npz")
+    zi, zt = torch.from_numpy(g["zimg"]).to(DEV), torch.from_numpy(g["ztxt"]).to(DEV)
+    got = ev.retrieval_recall(zi, zt, list(g["corr"]))
+    for n, k in enumerate(g["thresholds"]):
+        assert abs(got[f"txt2img/Recall@{k}"] - g["t2i"][n]) < 1e-7, k
+        assert abs(got[f"img2txt/Recall@{k}"] - g["i2t"][n]) < 1e-7, k
+    emb = torch.from_numpy(g["zs_text_norm"]).to(DEV)
+    C_, T_ = int(g["zs_classes"]), int(g["zs_templates"])
+    out = torch.empty(C_, emb.shape[1], dtype=torch.float32, device=DEV)
+    check(_lib.load().ov_class_mean_normalize(ptr(emb), ptr(out), C_, T_, emb.shape[1], stream_ptr()), "ov_class_mean_normalize")
+    np.testing.assert_allclose(out.T.cpu().numpy(), g["zs_weights"], atol=2e-6)
+
+
 def test_device_preprocess_bit_exact():
     """SURVEY.md §8f row 2 (image half): HIP resize + ToTensor + Normalize against Pillow's committed outputs (uint8 stage via the
     float output: x / 255 and (x - mean) / std are exact IEEE ops) and against the numpy oracle on odd geometries."""
@@ -580,3 +599,23 @@ def test_zero_shot_cli_with_text_prompts(tiny, tmp_path, capsys):
     rc = zero_shot.main(["--use_model", str(mdir), "--image_dir", str(idir), "--prompts", "a photo of a cat|a photo of a dog|a remote control"])
     out = capsys.readouterr().out
     assert rc == 0 and "Best Image Per Text" in out and "a photo of a dog" in out and out.count("cosine:") == 9
+
+
+def test_step_enqueues_without_host_synchronisation(tiny):
+    """ABI 2: the logit scale reaches ov_clip_loss / ov_logits as a device scalar, so forward + InfoNCE enqueue without draining
+    the stream (the reference never leaves the device either: loss.py:120-131).  torch raises on any synchronising call in
+    sync-debug mode 'error'; the library itself holds no hipStreamSynchronize / blocking copy on this path."""
+    img = synth.make_images(8, 160, seed=6).to(DEV)
+    tok = synth.make_captions(8, seed=6).to(DEV)
+    loss_fn = ClipLoss()
+    want = float(loss_fn(*tiny(img, tok)))                     # warm-up: packs weights, sizes workspaces
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        ni, nt, s = tiny(img, tok)
+        loss = loss_fn(ni, nt, s)
+        li, lt = tiny.get_logits(img, tok)
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    assert abs(float(loss) - want) < 1e-6
+    assert torch.isfinite(li).all()

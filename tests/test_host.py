@@ -113,3 +113,23 @@ def test_config_dir_roundtrip(tmp_path):
     (tmp_path / "open_clip_config.json").write_text(json.dumps({"model_cfg": cfg, "preprocess_cfg": ovcfg.DEFAULT_PREPROCESS}))
     mc, pp = ovcfg.load_config_dir(str(tmp_path))
     assert mc == cfg and pp["mean"][0] == pytest.approx(0.48145466)
+
+
+def test_invalidate_packed_after_dot_data_writes():
+    """In-place writes through .data leave _version and data_ptr unchanged, so the packed-weight cache cannot see them:
+    invalidate_packed() (module-level or CLIP.invalidate_packed) must force a rebuild; load_state_dict does it by itself."""
+    from openvision_amd import model as M
+    lin = M.Linear(64, 8)
+    w0, _ = lin.packed()
+    assert lin.packed()[0] is w0                               # cached
+    lin.weight.data.mul_(2.0)                                   # invisible to (data_ptr, _version)
+    assert lin.packed()[0] is w0                               # stale: this is the documented hazard
+    M.invalidate_packed()
+    w1, _ = lin.packed()
+    assert w1 is not w0 and torch.equal(w1.float(), (w0.float() * 2).to(torch.bfloat16).float())
+    cfg = preset("vit-tiny-patch16-160")
+    m = create_model(cfg, state_dict=synth.make_state_dict(cfg))
+    ln = m.visual.ln_post.packed()
+    m.load_state_dict(synth.make_state_dict(cfg, seed=1))
+    assert m.visual.ln_post.packed() is not ln
+    m.invalidate_packed()
