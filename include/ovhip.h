@@ -281,6 +281,8 @@ int ov_profile_read(int cls, double* total_ms, int* count, double* total_rows /*
 
 /* Diagnostics: device buffer [workgroup][slots][8] of s_memtime stamps written by the persistent GEMM (NULL = off). */
 int ov_debug_gemm_stamps(unsigned long long* buf, int slots);
+/* Diagnostics: per-wave epilogue timeline [workgroup][slots][8 waves][8] (NULL = off; `slots` as given to ov_debug_gemm_stamps). */
+int ov_debug_gemm_wave_stamps(unsigned long long* wbuf);
 
 /* ---- tower level (the resblock loop and the two encoders) --------------------------------------- */
 

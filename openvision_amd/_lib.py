@@ -120,6 +120,7 @@ SIGNATURES = {
     "ov_profile_enable": (c_int, [C.c_uint, c_int]),
     "ov_profile_read": (c_int, [c_int, C.POINTER(C.c_double), C.POINTER(c_int), C.POINTER(C.c_double)]),
     "ov_debug_gemm_stamps": (c_int, [c_void_p, c_int]),
+    "ov_debug_gemm_wave_stamps": (c_int, [c_void_p]),
     "ov_tower_create": (c_void_p, [C.POINTER(TowerCfg)]),
     "ov_tower_destroy": (None, [c_void_p]),
     "ov_tower_set_block": (c_int, [c_void_p, c_int, C.POINTER(BlockWeights)]),

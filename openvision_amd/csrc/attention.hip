@@ -310,14 +310,15 @@ __global__ __launch_bounds__(DEEP ? 512 : 640, DEEP ? 2 : 3) void attn_fwd_hd64_
     const bool lone_key = lone_on && (L & 31) == 1 && (nk_tiles & 1) && nk_tiles > 1;   // an odd last key tile that holds a single key
     const int n = (a.nheads - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;     // heads of this workgroup
     if (n <= 0) return;
-    const float inv8 = OUT8 ? 448.0f / (2.0f * fmaxf(*a.out_amax, 1e-30f)) : 1.0f;
-    const float next_thr = (OUT8 && a.amax_next != nullptr) ? *a.amax_next : 0.f;   // read once: no global load inside the head loop
+    // wave-uniform scalars, pinned to SGPRs (v_readfirstlane): as VGPRs they were two of the loop invariants the 9-wave variant spilled
+    const float inv8 = OUT8 ? __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(448.0f / (2.0f * fmaxf(*a.out_amax, 1e-30f))))) : 1.0f;
+    const float next_thr = (OUT8 && a.amax_next != nullptr)       // read once: no global load inside the head loop
+                               ? __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(*a.amax_next))) : 0.f;
 
-    const int k_lane = r * 128;
-    const int k_sw = (r >> 1) & 7;
-    int ksw[4];
-#pragma unroll
-    for (int st = 0; st < 4; ++st) ksw[st] = k_lane + (((2 * st + h2) ^ k_sw) << 4);
+    // K fragment st of this lane sits at row r, 16-byte chunk (2 st + h2) ^ k_sw, k_sw = (r >> 1) & 7: byte offset
+    // kb ^ (32 st) with kb = r * 128 + ((h2 ^ k_sw) << 4) (bits 5-6 of everything else are zero).  ONE register; the XOR is
+    // applied to the tile's address inside load_k (4 VALU ops per tile) instead of keeping four loop-invariant offsets live.
+    const int kb = r * 128 + ((h2 ^ ((r >> 1) & 7)) << 4);
     const int vi = lane & 15, vg = (lane >> 4) & 1;
     const int v_lane0 = KC * 128 + (4 * h2 + (vi >> 2)) * 64 + (16 * vg + 4 * (vi & 3)) * 2;   // d half 0
     const int v_lane1 = v_lane0 + KC * 64;                                                    // d half 1
@@ -340,11 +341,25 @@ __global__ __launch_bounds__(DEEP ? 512 : 640, DEEP ? 2 : 3) void attn_fwd_hd64_
     // past the last query replicate query L-1 and rewrite its row with identical values) and are inline asm.
     // The Q loads are inline asm too (hipcc would drain the LDS-DMA queue at the first use of an ordinary load); the wait
     // names their registers "+v" in the same basic block, before any loop-carried copy can be made of them.
+    // Per-lane parts of the Q-row and output-row addresses as 32-bit BYTE offsets from a wave-uniform (SGPR) base per head
+    // (saddr form of the global instructions): two VGPRs instead of two 64-bit pointers kept live across the whole head loop.
+    // The launcher guarantees L * ld * 2 < 2^31 for both pitches.
+    // They are RE-derived from the lane id at each use (once per head, ~6 VALU ops) behind an opaque asm: as loop invariants hipcc
+    // hoisted them out of the head loop and then spilled them in the 9-wave variant (168 VGPRs).
+    auto row_offset = [&](int ld, int per_h2, unsigned bytes) {
+        unsigned lf = (unsigned)lane;
+        asm volatile("" : "+v"(lf));
+        int qr = q0 + (int)(lf & 31u);
+        qr = qr < L ? qr : L - 1;
+        return (unsigned)(qr * ld + per_h2 * (int)(lf >> 5)) * bytes;
+    };
     auto load_q = [&](u32x4_t (&q)[4], int bh) {
-        const ov_bf16* qp = head_base(bh) + (int64_t)qrow * a.ldq + 8 * h2;
-#pragma unroll
-        for (int st = 0; st < 4; ++st)
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(q[st]) : "v"(qp + 16 * st) : "memory");
+        const ov_bf16* qb = head_base(bh);                         // wave-uniform
+        const unsigned qoff = row_offset((int)a.ldq, 8, 2u);
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(q[0]) : "v"(qoff), "s"(qb) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:32" : "=v"(q[1]) : "v"(qoff), "s"(qb) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "=v"(q[2]) : "v"(qoff), "s"(qb) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:96" : "=v"(q[3]) : "v"(qoff), "s"(qb) : "memory");
     };
     stage_head(a, blockIdx.x, smem, wave, lane, blockDim.x);
     u32x4_t qn[4];
@@ -372,9 +387,9 @@ __global__ __launch_bounds__(DEEP ? 512 : 640, DEEP ? 2 : 3) void attn_fwd_hd64_
         // MFMA->VALU->MFMA dependency chain of one tile are covered by the other's work; an odd last tile runs alone.
         bf16x8_t kfa[4], kfb[4];
         auto load_k = [&](bf16x8_t (&kf)[4], int kt) {
-            const char* kp = ks + kt * 4096;
+            const unsigned kp = (unsigned)(kt * 4096 + kb);          // slot bases are multiples of 256: the XOR stays inside the row
 #pragma unroll
-            for (int st = 0; st < 4; ++st) kf[st] = *(const bf16x8_t*)(kp + ksw[st]);
+            for (int st = 0; st < 4; ++st) kf[st] = *(const bf16x8_t*)(ks + (kp ^ (unsigned)(st * 32)));
         };
         auto mask_tail = [&](f32x16_t& sc, int kt) {
             if (kt * 32 + 32 > L) {
@@ -402,10 +417,16 @@ __global__ __launch_bounds__(DEEP ? 512 : 640, DEEP ? 2 : 3) void attn_fwd_hd64_
             const unsigned va0 = ks_u + kt * 2048 + v_lane0, va1 = ks_u + kt * 2048 + v_lane1;
             if (!DEEP) load_k(kfb, kt + 1);                            // second tile's K: covered by the first tile's MFMAs
             u32x2_t vt[8], vu[8];
-            vt[0] = tr_read_off<0>(va0);    vt[1] = tr_read_off<512>(va0);
-            vt[2] = tr_read_off<0>(va1);    vt[3] = tr_read_off<512>(va1);
-            vt[4] = tr_read_off<1024>(va0); vt[5] = tr_read_off<1536>(va0);
-            vt[6] = tr_read_off<1024>(va1); vt[7] = tr_read_off<1536>(va1);
+            auto read_vt = [&]() {
+                vt[0] = tr_read_off<0>(va0);    vt[1] = tr_read_off<512>(va0);
+                vt[2] = tr_read_off<0>(va1);    vt[3] = tr_read_off<512>(va1);
+                vt[4] = tr_read_off<1024>(va0); vt[5] = tr_read_off<1536>(va0);
+                vt[6] = tr_read_off<1024>(va1); vt[7] = tr_read_off<1536>(va1);
+            };
+            // 9+ waves (3 per SIMD: 168 VGPRs): the first tile's V fragments are fetched behind the S MFMAs instead of in front
+            // of them -- still a whole softmax ahead of their use, and 16 registers fewer while both K tiles are live (the kernel
+            // spilled 10 VGPRs otherwise, which the inline-asm loads and counted waits must not meet: tests/test_build_scratch.py)
+            if (DEEP) read_vt();
             if (DEEP) {
                 vu[0] = tr_read_off<2048>(va0); vu[1] = tr_read_off<2560>(va0);
                 vu[2] = tr_read_off<2048>(va1); vu[3] = tr_read_off<2560>(va1);
@@ -419,6 +440,7 @@ __global__ __launch_bounds__(DEEP ? 512 : 640, DEEP ? 2 : 3) void attn_fwd_hd64_
             for (int st = 0; st < 4; ++st) sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfa[st], qf[st], sa, 0, 0, 0);
 #pragma unroll
             for (int st = 0; st < 4; ++st) sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfb[st], qf[st], sb, 0, 0, 0);
+            if (!DEEP) read_vt();
             if (kt + 2 < nk_tiles) load_k(kfa, kt + 2);                // next step's first tile, fetched under the softmax
             if (DEEP && kt + 3 < nk_tiles) load_k(kfb, kt + 3);
             mask_tail(sb, kt + 1);
@@ -519,7 +541,12 @@ __global__ __launch_bounds__(DEEP ? 512 : 640, DEEP ? 2 : 3) void attn_fwd_hd64_
             }
         } else if (nk_tiles & 1) {
             const int kt = nk_tiles - 1;
-            const unsigned va0 = ks_u + kt * 2048 + v_lane0, va1 = ks_u + kt * 2048 + v_lane1;
+            // the lane's V-image offset, re-derived behind an opaque asm (see row_offset: not a second live copy of v_lane0)
+            unsigned lf = (unsigned)lane;
+            asm volatile("" : "+v"(lf));
+            const unsigned vif = lf & 15u, vgf = (lf >> 4) & 1u, h2f = lf >> 5;
+            const unsigned vl0 = (unsigned)KC * 128u + (4u * h2f + (vif >> 2)) * 64u + (16u * vgf + 4u * (vif & 3u)) * 2u;
+            const unsigned va0 = ks_u + kt * 2048 + vl0, va1 = va0 + (unsigned)KC * 64u;
             u32x2_t vt[8];
             vt[0] = tr_read_off<0>(va0);    vt[1] = tr_read_off<512>(va0);
             vt[2] = tr_read_off<0>(va1);    vt[3] = tr_read_off<512>(va1);
@@ -573,25 +600,31 @@ __global__ __launch_bounds__(DEEP ? 512 : 640, DEEP ? 2 : 3) void attn_fwd_hd64_
                 if (lane == 0 && lm > next_thr) atomicMax((unsigned*)a.amax_next, __float_as_uint(lm));
             }
             inv *= inv8;
-            unsigned char* op = (unsigned char*)a.out + ((int64_t)(bh / a.H) * L + qrow) * a.ldo + (bh % a.H) * 64 + 4 * h2;
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const unsigned w0 = pack_fp8x4(o0[4 * gq] * inv, o0[4 * gq + 1] * inv, o0[4 * gq + 2] * inv, o0[4 * gq + 3] * inv);
-                const unsigned w1 = pack_fp8x4(o1[4 * gq] * inv, o1[4 * gq + 1] * inv, o1[4 * gq + 2] * inv, o1[4 * gq + 3] * inv);
-                asm volatile("global_store_dword %0, %1, off" :: "v"(op + 8 * gq), "v"(w0) : "memory");
-                asm volatile("global_store_dword %0, %1, off\n\ts_nop 0" :: "v"(op + 32 + 8 * gq), "v"(w1) : "memory");
+            const unsigned char* ob = (const unsigned char*)a.out + (int64_t)(bh / a.H) * L * a.ldo + (bh % a.H) * 64;   // uniform
+            const unsigned ooff = row_offset((int)a.ldo, 4, 1u);
+#define OV_ST8(GQ)                                                                                                         \
+            {                                                                                                              \
+                const unsigned w0 = pack_fp8x4(o0[4 * GQ] * inv, o0[4 * GQ + 1] * inv, o0[4 * GQ + 2] * inv, o0[4 * GQ + 3] * inv); \
+                const unsigned w1 = pack_fp8x4(o1[4 * GQ] * inv, o1[4 * GQ + 1] * inv, o1[4 * GQ + 2] * inv, o1[4 * GQ + 3] * inv); \
+                asm volatile("global_store_dword %0, %1, %2 offset:%3" :: "v"(ooff), "v"(w0), "s"(ob), "n"(8 * GQ) : "memory");        \
+                asm volatile("global_store_dword %0, %1, %2 offset:%3\n\ts_nop 0" :: "v"(ooff), "v"(w1), "s"(ob), "n"(32 + 8 * GQ) : "memory"); \
             }
+            OV_ST8(0) OV_ST8(1) OV_ST8(2) OV_ST8(3)
+#undef OV_ST8
         } else {
-            ov_bf16* op = a.out + ((int64_t)(bh / a.H) * L + qrow) * a.ldo + (bh % a.H) * 64 + 4 * h2;
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const u32x2_t w0 = {pack_bf16x2(o0[4 * gq] * inv, o0[4 * gq + 1] * inv),
-                                    pack_bf16x2(o0[4 * gq + 2] * inv, o0[4 * gq + 3] * inv)};
-                const u32x2_t w1 = {pack_bf16x2(o1[4 * gq] * inv, o1[4 * gq + 1] * inv),
-                                    pack_bf16x2(o1[4 * gq + 2] * inv, o1[4 * gq + 3] * inv)};
-                asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(op + 8 * gq), "v"(w0) : "memory");
-                asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 0" :: "v"(op + 32 + 8 * gq), "v"(w1) : "memory");
+            const ov_bf16* ob = a.out + (int64_t)(bh / a.H) * L * a.ldo + (bh % a.H) * 64;                       // uniform
+            const unsigned ooff = row_offset((int)a.ldo, 4, 2u);
+#define OV_ST16(GQ)                                                                                                         \
+            {                                                                                                               \
+                const u32x2_t w0 = {pack_bf16x2(o0[4 * GQ] * inv, o0[4 * GQ + 1] * inv),                                      \
+                                    pack_bf16x2(o0[4 * GQ + 2] * inv, o0[4 * GQ + 3] * inv)};                                  \
+                const u32x2_t w1 = {pack_bf16x2(o1[4 * GQ] * inv, o1[4 * GQ + 1] * inv),                                      \
+                                    pack_bf16x2(o1[4 * GQ + 2] * inv, o1[4 * GQ + 3] * inv)};                                  \
+                asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3" :: "v"(ooff), "v"(w0), "s"(ob), "n"(16 * GQ) : "memory");      \
+                asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3\n\ts_nop 0" :: "v"(ooff), "v"(w1), "s"(ob), "n"(64 + 16 * GQ) : "memory"); \
             }
+            OV_ST16(0) OV_ST16(1) OV_ST16(2) OV_ST16(3)
+#undef OV_ST16
         }
         asm volatile("s_waitcnt vmcnt(8)" : "+v"(qn[0]), "+v"(qn[1]), "+v"(qn[2]), "+v"(qn[3]) :: "memory");
     }
@@ -1006,7 +1039,7 @@ int attention_impl(const ov_bf16* qkv, int64_t ld_qkv, ov_bf16* out, int64_t ld_
     const int lp = a.nqt * 32;
     static int force_v1 = -1;
     if (force_v1 < 0) { const char* e = getenv("OVHIP_ATTN_V1"); force_v1 = (e && e[0] == '1') ? 1 : 0; }
-    if (lp <= 320 && !force_v1 && (int64_t)L * ld_qkv * 2 < 0x7fffffffLL) {
+    if (lp <= 320 && !force_v1 && (int64_t)L * ld_qkv * 2 < 0x7fffffffLL && (int64_t)L * ld_out * 2 < 0x7fffffffLL) {
         AttnPArgs p;
         p.qkv = qkv; p.ldq = ld_qkv; p.out = out; p.ldo = ld_out;
         p.L = L; p.H = H; p.nqt = a.nqt; p.KC = lp; p.nheads = B * H; p.scale_log2 = a.scale_log2; p.out_amax = out_amax; p.amax_next = amax_next;

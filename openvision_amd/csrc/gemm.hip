@@ -34,8 +34,11 @@ struct GemmArgs {
     const float* rowstats;          // LN fold: {mean, rstd} per row of A
     unsigned long long* stamps;     // diagnostics only (ov_debug_gemm_stamps): [block][tile slot][4] s_memtime values
     int stamp_slots;
+    unsigned long long* wstamps;    // diagnostics only: per-wave epilogue timeline [block][tile slot][wave][8]
     int ngroup;                     // persistent kernel: n-tiles per group of the XCD tile walk (== tiles_n: plain n-fastest walk)
     int64_t batch_a, batch_w, batch_c;   // gemm_bf16_pp with gridDim.y > 1: element strides of A, W, C per batch entry (split-K partials)
+    int stagger, stagger_classes;        // persistent kernel: start delay (shader cycles) per class (bid >> 3) % classes (0 = off)
+    int epi_prio;                        // persistent kernel: waves 4-7 (the arbitration losers) run their epilogue at s_setprio 1
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -354,13 +357,150 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp(const GemmArgs g_in)
 //     pass i-1.  DS operations of one wave execute in order, so the passes need no waits beyond data use;
 //   * the two wave groups re-align for the epilogue (both halves of every SIMD share the VALU work) and re-stagger
 //     by one barrier afterwards.
-constexpr int IMG_OFF = SMEM_BYTES;                  // 8 wave-local 2-KiB transposition images (16 rows x 64 n bf16)
-constexpr int PRM_OFF = IMG_OFF + 8 * 2048;          // two 4-KiB parameter blocks: bias[256] f32 | colsum[256] f32 | rowstats[256][2] f32
-constexpr int SMEM_PERSIST = PRM_OFF + 2 * 4096;     // 152 KiB of the CU's 160
+constexpr int PRM_OFF = SMEM_BYTES;                  // two 4-KiB parameter blocks: bias[256] f32 | colsum[256] f32 | rowstats[256][2] f32
+constexpr int IMG_OFF = PRM_OFF + 2 * 4096;          // DIRECT == false only: 8 wave-local 2-KiB transposition images (16 rows x 64 n bf16)
+constexpr int SMEM_PERSIST = IMG_OFF + 8 * 2048;     // 152 KiB of the CU's 160 (136 KiB without the images)
 
+// Epilogue of the persistent kernel.  After the MFMAs a lane (fr = lane & 15, fq = lane >> 4) holds, for each of its 8 fragment rows i
+// and 4 column blocks j, four consecutive n of ONE output row: acc[i][j][0..3] = C[i*16 + fr][j*16 + fq*4 + 0..3].  Packed to bf16
+// that is 8 bytes per (i, j).  Two v_permlane16_swap per pair of column blocks (j0, j0 + 1) exchange the 8 bytes of block j0 + 1 in
+// the even 16-lane rows with the 8 bytes of block j0 in the odd rows, after which every lane owns 16 CONTIGUOUS bytes of its row:
+//     fq 0: n  0- 7 | fq 2: n  8-15 | fq 1: n 16-23 | fq 3: n 24-31      (+ 32 for the pair j0 = 2)
+// so one global_store_dwordx4 writes 64 contiguous bytes of each of the wave's 16 rows -- no transposition through LDS (the 8-pass
+// LDS image of the previous version cost 4 ds_write_b64 + 2 ds_read_b128 and an LDS round trip per pass).
 template <int EPI, bool FOLD>
-__device__ __forceinline__ void epilogue_stream(const GemmArgs& g, f32x4_t (&acc)[8][4], char* img, const char* prm,
-                                                int64_t m0, int n0, int wave, int lane, bool edge) {
+__device__ __forceinline__ void epilogue_stream(const GemmArgs& g, f32x4_t (&acc)[8][4], const char* prm,
+                                                int64_t m0, int n0, int wave, int lane, bool edge, unsigned long long* wst) {
+    const int wm = wave >> 2, wn = wave & 3;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int cb = (fq & 1) * 16 + (fq >> 1) * 8;                 // column of this lane's 16-byte chunk inside a 32-column pair
+    const int n_lo = n0 + wn * 64 + cb;                           // pair 0; pair 1 is + 32
+    const bool ncol0 = n_lo + 8 <= g.N, ncol1 = n_lo + 40 <= g.N;
+    // Residual rows (unpredicated, clamped addresses -- a predicated load makes hipcc serialise the loads behind
+    // vmcnt(0)).  Every load of the epilogue is issued before its first store: rows of passes 0-3 now, rows of passes
+    // 4-7 once four accumulator rows have been retired (register room), and only then the first store.
+    u32x4_t rv[8][2];
+    const int nc0 = ncol0 ? n_lo : g.N - 8, nc1 = ncol1 ? n_lo + 32 : g.N - 8;
+    auto load_resid = [&](int i) {      // inline asm: the waits below are counted by hand (hipcc would use vmcnt(0))
+        unsigned m = (unsigned)m0 + wm * 128 + i * 16 + fr;
+        m = m < (unsigned)g.M ? m : (unsigned)g.M - 1;
+        const unsigned rrow = g.resid_mod ? (m % (unsigned)g.resid_mod) + g.resid_off : m;
+        const ov_bf16* src = g.R + (int64_t)rrow * g.ldr;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rv[i][0]) : "v"(src + nc0));
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rv[i][1]) : "v"(src + nc1));
+    };
+    if (EPI == OV_EPI_BIAS_RESIDUAL) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) load_resid(i);
+    }
+    // Parameter block reads are inline asm: as plain LDS loads hipcc orders them behind every LDS-DMA in flight
+    // (s_waitcnt vmcnt(0)), i.e. behind the next tile's K-tile 1 that was issued a moment ago.
+    f32x4_t bq[4], sq[4];
+    f32x2_t stq[8];
+    const unsigned pa = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(prm + (wn * 64 + fq * 4) * 4);
+    const unsigned ra = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(prm + 2048 + (wm * 128 + fr) * 8);
+    // (no branch between a read and its wait: a merge point would make hipcc copy the destination registers early)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bq[j]) : "v"(pa), "n"(j * 64));
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(sq[j]) : "v"(pa), "n"(1024 + j * 64));
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(stq[i]) : "v"(ra), "n"(i * 128));
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]), "+v"(sq[0]), "+v"(sq[1]), "+v"(sq[2]), "+v"(sq[3]));
+    asm volatile("" : "+v"(stq[0]), "+v"(stq[1]), "+v"(stq[2]), "+v"(stq[3]), "+v"(stq[4]), "+v"(stq[5]), "+v"(stq[6]), "+v"(stq[7]));
+    if (wst != nullptr && lane == 0) wst[2] = __builtin_amdgcn_s_memtime();
+    const bool has_bias = g.bias != nullptr;
+    float bv[4][4], sv[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            bv[j][e] = has_bias ? bq[j][e] : 0.f;
+            sv[j][e] = FOLD ? sq[j][e] : 0.f;
+        }
+    u32x4_t vo[8][2];
+    auto put = [&](int i) {
+        const unsigned m = (unsigned)m0 + wm * 128 + i * 16 + fr;
+        const unsigned orow = g.out_group ? m + m / (unsigned)g.out_group + 1 : m;
+        ov_bf16* dst = g.C + (int64_t)orow * g.ldc + n_lo;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            u32x4_t o = vo[i][h];
+            if (EPI == OV_EPI_BIAS_RESIDUAL) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    o[e] = pack_bf16x2(bf16lo_to_f32(o[e]) + bf16lo_to_f32(rv[i][h][e]),
+                                       bf16hi_to_f32(o[e]) + bf16hi_to_f32(rv[i][h][e]));
+            }
+            if (m < (unsigned)g.M && (h ? ncol1 : ncol0)) *(u32x4_t*)(dst + h * 32) = o;
+        }
+    };
+    // vmcnt is counted by hand around the asm residual loads: `edge` tiles issue fewer than 2 stores per pass, so they
+    // fall back to a full drain
+    auto wait_resid = [&](int i0, int i1, int younger) {
+        if (edge) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (younger == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+#pragma unroll
+        for (int k = i0; k < i1; ++k) asm volatile("" : "+v"(rv[k][0]), "+v"(rv[k][1]));
+    };
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (EPI == OV_EPI_BIAS_RESIDUAL && i == 4) {
+#pragma unroll
+            for (int k = 4; k < 8; ++k) load_resid(k);
+        }
+        f32x2_t nm = {0.f, 0.f}, rs = {1.f, 1.f};
+        if (FOLD) {
+            nm = f32x2_t{-stq[i][0], -stq[i][0]};
+            rs = f32x2_t{stq[i][1], stq[i][1]};
+        }
+        u32x2_t pk[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x2_t v01 = f32x2_t{acc[i][j][0], acc[i][j][1]};
+            f32x2_t v23 = f32x2_t{acc[i][j][2], acc[i][j][3]};
+            if (FOLD) {      // rstd * (acc - mean * colsum) + cvec, as two explicit FMAs (identical in every kernel variant)
+                v01 = __builtin_elementwise_fma(f32x2_t{sv[j][0], sv[j][1]}, nm, v01);
+                v23 = __builtin_elementwise_fma(f32x2_t{sv[j][2], sv[j][3]}, nm, v23);
+                v01 = __builtin_elementwise_fma(v01, rs, f32x2_t{bv[j][0], bv[j][1]});
+                v23 = __builtin_elementwise_fma(v23, rs, f32x2_t{bv[j][2], bv[j][3]});
+            } else {
+                v01 += f32x2_t{bv[j][0], bv[j][1]};
+                v23 += f32x2_t{bv[j][2], bv[j][3]};
+            }
+            if (EPI == OV_EPI_BIAS_GELU_ERF) gelu_erf_f2x2(v01, v23);
+            if (EPI == OV_EPI_BIAS_GELU_TANH) { v01 = gelu_tanh_f2(v01); v23 = gelu_tanh_f2(v23); }
+            pk[j] = u32x2_t{pack_bf16x2(v01[0], v01[1]), pack_bf16x2(v23[0], v23[1])};
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            // odd 16-lane rows of block 2h <-> even rows of block 2h + 1 (one swap per dword)
+            const u32x2_t s0 = __builtin_amdgcn_permlane16_swap(pk[2 * h][0], pk[2 * h + 1][0], false, false);
+            const u32x2_t s1 = __builtin_amdgcn_permlane16_swap(pk[2 * h][1], pk[2 * h + 1][1], false, false);
+            vo[i][h] = u32x4_t{s0[0], s1[0], s0[1], s1[1]};
+        }
+        if (EPI == OV_EPI_BIAS_RESIDUAL) {
+            // in flight behind the rows waited for: i == 3 -> after the second batch of loads at i == 4.  Stores start once every
+            // load is out: at i == 4 the rows of passes 4-7 (8 loads) are younger than those of passes 0-3; later, per pass, the
+            // remaining row loads plus the stores of all earlier passes = 14 every time
+            if (i == 4) { wait_resid(0, 4, 8); put(0); put(1); put(2); put(3); }
+            if (i >= 4) { wait_resid(i, i + 1, 14); put(i); }
+        } else {
+            put(i);
+        }
+        if (wst != nullptr && lane == 0 && (i == 1 || i == 4)) wst[i == 1 ? 3 : 4] = __builtin_amdgcn_s_memtime();
+    }
+    if (wst != nullptr && lane == 0) wst[5] = __builtin_amdgcn_s_memtime();
+}
+
+// The same epilogue with the 16-byte stores made row-contiguous through a wave-local LDS image (8 lanes x 16 B = one 128-B line):
+// coalesced stores (16 TA cycles per instruction against ~70 for the row-per-lane form above), at the price of the LDS round trip.
+template <int EPI, bool FOLD>
+__device__ __forceinline__ void epilogue_stream_lds(const GemmArgs& g, f32x4_t (&acc)[8][4], char* img, const char* prm,
+                                                int64_t m0, int n0, int wave, int lane, bool edge, unsigned long long* wst) {
     const int wm = wave >> 2, wn = wave & 3;
     const int fr = lane & 15, fq = lane >> 4;
     const int er = lane >> 3, ec = lane & 7;
@@ -402,6 +542,7 @@ __device__ __forceinline__ void epilogue_stream(const GemmArgs& g, f32x4_t (&acc
     asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]), "+v"(sq[0]), "+v"(sq[1]), "+v"(sq[2]), "+v"(sq[3]));
     asm volatile("" : "+v"(stq[0]), "+v"(stq[1]), "+v"(stq[2]), "+v"(stq[3]), "+v"(stq[4]), "+v"(stq[5]), "+v"(stq[6]), "+v"(stq[7]));
+    if (wst != nullptr && lane == 0) wst[2] = __builtin_amdgcn_s_memtime();
     const bool has_bias = g.bias != nullptr;
     float bv[4][4], sv[4][4];
 #pragma unroll
@@ -486,15 +627,17 @@ __device__ __forceinline__ void epilogue_stream(const GemmArgs& g, f32x4_t (&acc
             vo[i][0] = *(const u32x4_t*)(rd);
             vo[i][1] = *(const u32x4_t*)(rd + 1024);
         }
+        if (wst != nullptr && lane == 0 && (i == 1 || i == 4)) wst[i == 1 ? 3 : 4] = __builtin_amdgcn_s_memtime();
     }
+    if (wst != nullptr && lane == 0) wst[5] = __builtin_amdgcn_s_memtime();
 }
 
 template <int V> struct IntC { static constexpr int value = V; };
 struct TileSrc { const ov_bf16* a0; const ov_bf16* a1; const ov_bf16* w0; const ov_bf16* w1; };   // per-lane staging sources
 
-template <int EPI, bool FOLD>
+template <int EPI, bool FOLD, bool DIRECT>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist(const GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) char smem[SMEM_PERSIST];
+    __shared__ __attribute__((aligned(16))) char smem[DIRECT ? IMG_OFF : SMEM_PERSIST];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -523,6 +666,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist(const GemmArgs 
     const int nper = (G - xcd + 7) >> 3;
     int tcur = li;
     if (tcur >= xcnt) return;
+    if (g.stagger > 0) {
+        // De-synchronise the CUs of an XCD: in lockstep every CU reaches its epilogue at the same moment and the 4 MB an XCD then
+        // writes at once queue on its fabric link; classes start a fraction of a tile period apart so the bursts interleave.
+        const int cls = li % g.stagger_classes;
+        if (cls) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+            const unsigned long long want = (unsigned long long)cls * (unsigned)g.stagger;
+            while (__builtin_amdgcn_s_memtime() - t0 < want) __builtin_amdgcn_s_sleep(16);
+        }
+    }
 
     const int srow = tid >> 2;
     const int schunk = (tid & 3) ^ swz4(srow);
@@ -695,6 +848,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist(const GemmArgs 
         }
         ktile(IntC<3>{});
         stamp(1);
+        unsigned long long* wst = (g.wstamps != nullptr && titer < g.stamp_slots)
+                                      ? g.wstamps + (((size_t)bid * g.stamp_slots + titer) * 8 + wave) * 8 : nullptr;
+        if (wst != nullptr && lane == 0) wst[0] = __builtin_amdgcn_s_memtime();
         if (wm == 0) __builtin_amdgcn_s_barrier();                 // re-align: every wave is past its last COMPUTE segment
         stamp(2);
         if (has_next) {
@@ -708,13 +864,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist(const GemmArgs 
         }
         __builtin_amdgcn_sched_barrier(0);
         const bool edge = (m0 + BM > g.M) || (n0 + BN > g.N);      // an edge tile issues fewer than 16 stores per wave
-        epilogue_stream<EPI, FOLD>(g, acc, smem + IMG_OFF + wave * 2048, smem + PRM_OFF + pslot * 4096, m0, n0, wave, lane, edge);
+        if (wst != nullptr && lane == 0) wst[1] = __builtin_amdgcn_s_memtime();
+        if (g.epi_prio && wm == 1) __builtin_amdgcn_s_setprio(1);
+        if (DIRECT) epilogue_stream<EPI, FOLD>(g, acc, smem + PRM_OFF + pslot * 4096, m0, n0, wave, lane, edge, wst);
+        else epilogue_stream_lds<EPI, FOLD>(g, acc, smem + IMG_OFF + wave * 2048, smem + PRM_OFF + pslot * 4096, m0, n0, wave, lane, edge, wst);
+        if (g.epi_prio && wm == 1) __builtin_amdgcn_s_setprio(0);
         stamp(3);
         ++titer;
         if (!has_next) break;
         strict = edge;
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();                               // next K-tile 0 visible to all
+        if (wst != nullptr && lane == 0) wst[6] = __builtin_amdgcn_s_memtime();
         if (wm == 1) __builtin_amdgcn_s_barrier();                  // re-stagger
         cb ^= STAGE_BYTES;
         pslot ^= 1;
@@ -729,6 +890,7 @@ int num_cus() { return ov_num_cus(); }
 thread_local const float* g_colsum = nullptr;      // set by ov_gemm_ln around its call into ov_gemm
 thread_local const float* g_rowstats = nullptr;
 unsigned long long* g_stamps = nullptr;
+unsigned long long* g_wstamps = nullptr;
 int g_stamp_slots = 0;
 
 int gemm_variant() {       // 0 = persistent ping-pong (default), 1 = v1 two-stage, 2 = non-persistent ping-pong
@@ -757,6 +919,25 @@ int gemm_ngroup(int tiles_m, int tiles_n, int K) {
     return gsz;
 }
 
+// start stagger of the persistent kernel, cycles per class (OVHIP_GEMM_STAGGER; experiment knob, 0 = off)
+int gemm_stagger(int K) {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("OVHIP_GEMM_STAGGER"); v = e ? atoi(e) : 0; }
+    (void)K;
+    return v;
+}
+int gemm_stagger_classes() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("OVHIP_GEMM_STAGGER_CLASSES"); v = e ? atoi(e) : 4; if (v < 1) v = 1; }
+    return v;
+}
+
+int gemm_epi_prio() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("OVHIP_GEMM_EPI_PRIO"); v = e ? atoi(e) : 0; }
+    return v;
+}
+
 template <int EPI>
 int launch(GemmArgs a, hipStream_t st) {
     int var = gemm_variant();
@@ -775,10 +956,26 @@ int launch(GemmArgs a, hipStream_t st) {
     } else {
         const int ncu = num_cus();
         const dim3 grid(nwg < ncu ? nwg : ncu), blk(NTHREADS);
-        if (EPI != OV_EPI_BIAS_RESIDUAL && a.colsum != nullptr)
-            hipLaunchKernelGGL((gemm_bf16_persist<EPI, EPI != OV_EPI_BIAS_RESIDUAL>), grid, blk, 0, st, a);
-        else
-            hipLaunchKernelGGL((gemm_bf16_persist<EPI, false>), grid, blk, 0, st, a);
+        // Epilogue form.  GELU and residual epilogues: row-per-lane direct stores (no LDS round trip; the LDS form of these two
+        // needs more than the 256 VGPRs a wave has here and spills, which the hand-counted waits cannot tolerate).  Bias-only
+        // epilogue (QKV, projections): LDS-transposed coalesced stores measure faster in the model (9.5-9.8 against 10.0-10.3 ms per
+        // step for the QKV GEMMs); OVHIP_GEMM_EPI_DIRECT=1 selects the direct form there too.
+        constexpr bool CAN_FOLD = EPI != OV_EPI_BIAS_RESIDUAL;
+        if (EPI == OV_EPI_BIAS) {
+            static int direct0 = -1;
+            if (direct0 < 0) { const char* e = getenv("OVHIP_GEMM_EPI_DIRECT"); direct0 = (e && e[0] == '1') ? 1 : 0; }
+            if (a.colsum != nullptr) {
+                if (direct0) hipLaunchKernelGGL((gemm_bf16_persist<OV_EPI_BIAS, true, true>), grid, blk, 0, st, a);
+                else hipLaunchKernelGGL((gemm_bf16_persist<OV_EPI_BIAS, true, false>), grid, blk, 0, st, a);
+            } else {
+                if (direct0) hipLaunchKernelGGL((gemm_bf16_persist<OV_EPI_BIAS, false, true>), grid, blk, 0, st, a);
+                else hipLaunchKernelGGL((gemm_bf16_persist<OV_EPI_BIAS, false, false>), grid, blk, 0, st, a);
+            }
+        } else if (CAN_FOLD && a.colsum != nullptr) {
+            hipLaunchKernelGGL((gemm_bf16_persist<EPI, CAN_FOLD, true>), grid, blk, 0, st, a);
+        } else {
+            hipLaunchKernelGGL((gemm_bf16_persist<EPI, false, true>), grid, blk, 0, st, a);
+        }
     }
     OV_LAUNCH_CHECK();
     return OV_OK;
@@ -803,7 +1000,8 @@ extern "C" int ov_gemm(const ov_bf16* A, int64_t lda, const ov_bf16* W, int64_t 
     const int64_t tiles_n = (N + BN - 1) / BN;
     if (tiles_m * tiles_n > 0x7fffffffLL || M > 0x7fff0000LL) return OV_ERR_UNSUPPORTED;    // 32-bit row indices in the kernels
     GemmArgs a{A, W, bias, C, R, lda, ldw, ldc, ldr, M, N, K, (int)tiles_m, (int)tiles_n,
-               out_group, resid_mod, resid_off, g_colsum, g_rowstats, g_stamps, g_stamp_slots, gemm_ngroup((int)tiles_m, (int)tiles_n, K), 0, 0, 0};
+               out_group, resid_mod, resid_off, g_colsum, g_rowstats, g_stamps, g_stamp_slots, g_wstamps, gemm_ngroup((int)tiles_m, (int)tiles_n, K), 0, 0, 0,
+               gemm_stagger(K), gemm_stagger_classes(), gemm_epi_prio()};
     hipStream_t st = (hipStream_t)stream;
     switch (epilogue) {
         case OV_EPI_BIAS: return launch<OV_EPI_BIAS>(a, st);
@@ -824,8 +1022,8 @@ extern "C" int ov_gemm_batched(const ov_bf16* A, int64_t lda, int64_t stride_a, 
     if (((uintptr_t)A | (uintptr_t)W | (uintptr_t)C) & 15) return OV_ERR_INVALID;
     const int64_t tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     if (tiles_m * tiles_n > 0x7fffffffLL || M > 0x7fff0000LL) return OV_ERR_UNSUPPORTED;
-    GemmArgs a{A, W, nullptr, C, nullptr, lda, ldw, ldc, 0, M, N, K, (int)tiles_m, (int)tiles_n, 0, 0, 0, nullptr, nullptr, nullptr, 0,
-               (int)tiles_n, stride_a, stride_w, stride_c};
+    GemmArgs a{A, W, nullptr, C, nullptr, lda, ldw, ldc, 0, M, N, K, (int)tiles_m, (int)tiles_n, 0, 0, 0, nullptr, nullptr, nullptr, 0, nullptr,
+               (int)tiles_n, stride_a, stride_w, stride_c, 0, 1, 0};
     hipLaunchKernelGGL(gemm_bf16_pp<OV_EPI_BIAS>, dim3((unsigned)(tiles_m * tiles_n), (unsigned)batch), dim3(NTHREADS), 0,
                        (hipStream_t)stream, a);
     OV_LAUNCH_CHECK();
@@ -837,6 +1035,12 @@ extern "C" int ov_gemm_batched(const ov_bf16* A, int64_t lda, int64_t stride_a, 
 extern "C" int ov_debug_gemm_stamps(unsigned long long* buf, int slots) {
     g_stamps = buf;
     g_stamp_slots = buf ? slots : 0;
+    return OV_OK;
+}
+// Per-wave epilogue timeline: wbuf[block][slot][wave][8] = main loop end / epilogue_stream entry / parameters read / passes 1 and 4 done /
+// last store issued / past the tile-boundary barrier.  Needs ov_debug_gemm_stamps(buf, slots) as well (it carries `slots`).
+extern "C" int ov_debug_gemm_wave_stamps(unsigned long long* wbuf) {
+    g_wstamps = wbuf;
     return OV_OK;
 }
 
