@@ -330,14 +330,11 @@ __global__ __launch_bounds__(DEEP ? 512 : 640, DEEP ? 2 : 3) void attn_fwd_hd64_
         const int b = bh / a.H, h = bh - b * a.H;
         return a.qkv + (int64_t)b * L * a.ldq + h * 64;
     };
-    // VM-op order per head and wave: [LDS-DMA pieces of head j+1][4 Q loads of head j+1][8 output stores of head j].
-    // The wait in front of head j+1 is vmcnt(8): everything but the 8 youngest operations (the stores) has completed,
-    // so stores drain under the next head's MFMAs.  That count is exact because the 8 stores are never predicated:
-    // lanes past the last query replicate query L-1 (qrow clamp) and rewrite its row with identical values.
-    // VM-op order per head and wave: [LDS-DMA pieces of head j+1 (top of head j)] ... [4 Q loads of head j+1][8 stores of head j].
-    // The wait is vmcnt(8) at the END of head j, right behind the stores: everything but the 8 youngest operations (the
+    // VM-op order per head and wave: [LDS-DMA pieces of head j+1 (top of head j)] ... [4 Q loads of head j+1][NS stores of head j],
+    // NS = 4 (bf16 output: dwordx4 after the half-wave swap) or 8 (e4m3 output: dword stores).
+    // The wait is vmcnt(NS) at the END of head j, right behind the stores: everything but the NS youngest operations (the
     // stores) has completed, so the stores drain under the next head's MFMAs while its K/V pieces (issued a whole head
-    // earlier) and Q rows are known to have landed.  The count is exact because the 8 stores are never predicated (lanes
+    // earlier) and Q rows are known to have landed.  The count is exact because the stores are never predicated (lanes
     // past the last query replicate query L-1 and rewrite its row with identical values) and are inline asm.
     // The Q loads are inline asm too (hipcc would drain the LDS-DMA queue at the first use of an ordinary load); the wait
     // names their registers "+v" in the same basic block, before any loop-carried copy can be made of them.
@@ -612,21 +609,30 @@ __global__ __launch_bounds__(DEEP ? 512 : 640, DEEP ? 2 : 3) void attn_fwd_hd64_
             OV_ST8(0) OV_ST8(1) OV_ST8(2) OV_ST8(3)
 #undef OV_ST8
         } else {
+            // Widened store tail: after packing, a query row is split over the two half-waves (lane r: d 8g..8g+3, lane r+32:
+            // d 8g+4..8g+7 of group g).  One v_permlane32_swap per dword and pair of groups (g, g+1) leaves 16 contiguous bytes in
+            // every lane (lower half: d 8g..8g+7, upper half: d 8g+8..8g+15): FOUR global_store_dwordx4 per head instead of eight
+            // dwordx2 -- the tail is store-issue bound (each row-per-lane store is 64 separate requests), so half the instructions
+            // is half the time.
             const ov_bf16* ob = a.out + (int64_t)(bh / a.H) * L * a.ldo + (bh % a.H) * 64;                       // uniform
-            const unsigned ooff = row_offset((int)a.ldo, 4, 2u);
-#define OV_ST16(GQ)                                                                                                         \
+            const unsigned ooff = row_offset((int)a.ldo, 8, 2u);
+#define OV_ST16(O, P, BYTE_OFF)                                                                                              \
             {                                                                                                               \
-                const u32x2_t w0 = {pack_bf16x2(o0[4 * GQ] * inv, o0[4 * GQ + 1] * inv),                                      \
-                                    pack_bf16x2(o0[4 * GQ + 2] * inv, o0[4 * GQ + 3] * inv)};                                  \
-                const u32x2_t w1 = {pack_bf16x2(o1[4 * GQ] * inv, o1[4 * GQ + 1] * inv),                                      \
-                                    pack_bf16x2(o1[4 * GQ + 2] * inv, o1[4 * GQ + 3] * inv)};                                  \
-                asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3" :: "v"(ooff), "v"(w0), "s"(ob), "n"(16 * GQ) : "memory");      \
-                asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3\n\ts_nop 0" :: "v"(ooff), "v"(w1), "s"(ob), "n"(64 + 16 * GQ) : "memory"); \
+                const unsigned ax = pack_bf16x2(O[8 * P + 0] * inv, O[8 * P + 1] * inv), ay = pack_bf16x2(O[8 * P + 2] * inv, O[8 * P + 3] * inv); \
+                const unsigned bx = pack_bf16x2(O[8 * P + 4] * inv, O[8 * P + 5] * inv), by = pack_bf16x2(O[8 * P + 6] * inv, O[8 * P + 7] * inv); \
+                const auto sx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);                                       \
+                const auto sy = __builtin_amdgcn_permlane32_swap(ay, by, false, false);                                       \
+                const u32x4_t w = {sx[0], sy[0], sx[1], sy[1]};                                                               \
+                /* s_nop 1: a store of more than 8 bytes reads its data VGPRs late -- the next VALU write of them needs 2 wait states, and */ \
+                /* the assembler's hazard recogniser does not look inside inline asm */                                      \
+                asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" :: "v"(ooff), "v"(w), "s"(ob), "n"(BYTE_OFF) : "memory"); \
             }
-            OV_ST16(0) OV_ST16(1) OV_ST16(2) OV_ST16(3)
+            OV_ST16(o0, 0, 0) OV_ST16(o0, 1, 32) OV_ST16(o1, 0, 64) OV_ST16(o1, 1, 96)
 #undef OV_ST16
         }
-        asm volatile("s_waitcnt vmcnt(8)" : "+v"(qn[0]), "+v"(qn[1]), "+v"(qn[2]), "+v"(qn[3]) :: "memory");
+        // everything but this head's stores (8 dword stores with e4m3 output, 4 dwordx4 stores otherwise) has completed
+        if (OUT8) asm volatile("s_waitcnt vmcnt(8)" : "+v"(qn[0]), "+v"(qn[1]), "+v"(qn[2]), "+v"(qn[3]) :: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" : "+v"(qn[0]), "+v"(qn[1]), "+v"(qn[2]), "+v"(qn[3]) :: "memory");
     }
 }
 

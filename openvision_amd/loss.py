@@ -25,12 +25,12 @@ from ._lib import ptr, stream_ptr, check
 
 def gather_features(image_features: torch.Tensor, text_features: torch.Tensor, local_loss: bool = False,
                     gather_with_grad: bool = False, rank: int = 0, world_size: int = 1, use_horovod: bool = False,
-                    group=None) -> Tuple[torch.Tensor, torch.Tensor]:
+                    group=None, force: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """loss.py:19-63.  One all_gather_into_tensor of the packed [b, 2E] buffer instead of two list gathers;
     the result is identical: rows in rank order (torch.cat(gathered, dim=0), loss.py:60-61)."""
     if use_horovod:
         raise NotImplementedError("horovod transport is not supported; use torch.distributed (RCCL)")
-    if world_size == 1:
+    if world_size == 1 and not force:          # force: run the collective anyway (tests drive the RCCL path in a world of one)
         return image_features, text_features
     if not (dist.is_available() and dist.is_initialized()):
         raise RuntimeError("world_size > 1 needs an initialised torch.distributed process group (caller owns init)")
@@ -52,6 +52,7 @@ class ClipLoss(nn.Module):
             raise NotImplementedError("horovod transport is not supported; use torch.distributed (RCCL)")
         self.local_loss, self.gather_with_grad, self.cache_labels = local_loss, gather_with_grad, cache_labels
         self.rank, self.world_size, self.use_horovod = rank, world_size, use_horovod
+        self.always_collective = False   # tests only: take the world_size > 1 path (gather / reduce-scatter) in a world of one rank
         self._ws: Optional[torch.Tensor] = None
         self.last_terms: Optional[torch.Tensor] = None     # [4, b]: lse_img, diag_img, lse_txt, diag_txt
 
@@ -94,9 +95,9 @@ class ClipLoss(nn.Module):
         if not image_features.is_cuda:
             raise _lib.OvhipError("ClipLoss: features must live on an MI355X device (no CPU fallback)")
         scale = self._device_scale(logit_scale, image_features.device)
-        if self.world_size > 1:
+        if self.world_size > 1 or self.always_collective:
             all_img, all_txt = gather_features(image_features, text_features, self.local_loss, self.gather_with_grad,
-                                               self.rank, self.world_size, self.use_horovod, self.group)
+                                               self.rank, self.world_size, self.use_horovod, self.group, self.always_collective)
             if self.local_loss:
                 loss = self._loss_strips(image_features, text_features, all_img, all_txt, scale,
                                          image_features.shape[0] * self.rank)
@@ -128,17 +129,19 @@ class _ClipLossFn(torch.autograd.Function):
         ws, rank = mod.world_size, mod.rank
         img, txt = image_features.detach().float().contiguous(), text_features.detach().float().contiguous()
         b = img.shape[0]
-        if ws > 1:
-            all_img, all_txt = gather_features(img, txt, mod.local_loss, mod.gather_with_grad, rank, ws, mod.use_horovod, mod.group)
+        multi = ws > 1 or mod.always_collective
+        if multi:
+            all_img, all_txt = gather_features(img, txt, mod.local_loss, mod.gather_with_grad, rank, ws, mod.use_horovod, mod.group,
+                                               mod.always_collective)
         else:
             all_img, all_txt = img, txt
-        if ws > 1 and not mod.local_loss:
+        if multi and not mod.local_loss:
             x_img, x_txt, off = all_img, all_txt, 0          # every rank evaluates the global loss (loss.py:111-113)
         else:
             x_img, x_txt, off = img, txt, b * rank
         scale = mod._device_scale(logit_scale, img.device)
         loss = mod._loss_strips(x_img, x_txt, all_img, all_txt, scale, off)
-        ctx.mod, ctx.off, ctx.b = mod, off, b
+        ctx.mod, ctx.off, ctx.b, ctx.multi = mod, off, b, multi
         ctx.in_dtypes = (image_features.dtype, text_features.dtype, logit_scale.dtype)
         ctx.save_for_backward(x_img, x_txt, all_img, all_txt, mod.last_terms, scale)
         return loss
@@ -153,7 +156,8 @@ class _ClipLossFn(torch.autograd.Function):
         n = all_img.shape[0]
         # the gathered side carries gradient when it IS the local tensor (world_size 1), when the own chunk was put back
         # (not local_loss, loss.py:57-59) or when the gather itself is differentiable (gather_with_grad)
-        gathered_grad = ws == 1 or not mod.local_loss or mod.gather_with_grad
+        single = not ctx.multi                      # world of one without the collectives: both sides are the same tensors
+        gathered_grad = single or not mod.local_loss or mod.gather_with_grad
         d_img, d_txt = torch.empty_like(x_img), torch.empty_like(x_txt)
         d_all = torch.empty(2, n, e, dtype=torch.float32, device=x_img.device) if gathered_grad else None
         d_scale = torch.empty(1, dtype=torch.float32, device=x_img.device)
@@ -164,7 +168,7 @@ class _ClipLossFn(torch.autograd.Function):
                                         ptr(grad), ptr(d_img), ptr(d_txt), ptr(d_all[0]) if gathered_grad else None,
                                         ptr(d_all[1]) if gathered_grad else None, ptr(d_scale), ptr(wsb), nbytes, stream_ptr()),
               "ov_clip_loss_backward")
-        if ws == 1:
+        if single:
             g_img, g_txt = d_img + d_all[0], d_txt + d_all[1]
         elif mod.local_loss:
             g_img, g_txt = d_img, d_txt

@@ -160,6 +160,40 @@ def test_clip_loss_terms(b, N, E, off):
     assert abs(float(loss) - float(rank_loss)) < 2e-5
 
 
+@pytest.mark.timeout(600)
+def test_clip_loss_config5_shape_b4096_n32768():
+    """BASELINE.json config #5's loss shape (scripts/project/openvision/train.sh:18: global batch 32 768 = 8 ranks x 4 096): this
+    rank's [4096, 32768] logit strips both ways, never materialised.  The CPU oracle (fp32 torch, loss.py:102-131 arithmetic) checks
+    the per-row log-sum-exp and diagonal logit of 64 sampled rows per direction; the scalar loss must equal the mean of ALL rows'
+    (lse - diag) as the kernel itself reports them (so every row is tied to the sampled check by the same code path)."""
+    b, N, E, rank = 4096, 32768, 768, 5
+    g = torch.Generator(device="cpu").manual_seed(77)
+    ai = torch.nn.functional.normalize(torch.randn(N, E, generator=g), dim=-1)
+    at = torch.nn.functional.normalize(ai * 0.35 + torch.randn(N, E, generator=g) * 0.04, dim=-1)
+    off = rank * b
+    s = 1 / 0.07
+    dai, dat = ai.to(DEV), at.to(DEV)
+    img, txt = dai[off:off + b].contiguous(), dat[off:off + b].contiguous()
+    loss, terms = H.clip_loss(img, txt, dai, dat, s, off)
+    terms = terms.cpu()
+    rows = torch.randperm(b, generator=g)[:64]
+    li = s * ai[off + rows] @ at.T                                   # [64, N] on the CPU
+    lt = s * at[off + rows] @ ai.T
+    np.testing.assert_allclose(terms[0][rows].numpy(), torch.logsumexp(li, 1).numpy(), rtol=2e-5, atol=5e-5)
+    np.testing.assert_allclose(terms[1][rows].numpy(), li[torch.arange(64), off + rows].numpy(), rtol=2e-5, atol=5e-5)
+    np.testing.assert_allclose(terms[2][rows].numpy(), torch.logsumexp(lt, 1).numpy(), rtol=2e-5, atol=5e-5)
+    np.testing.assert_allclose(terms[3][rows].numpy(), lt[torch.arange(64), off + rows].numpy(), rtol=2e-5, atol=5e-5)
+    want = ((terms[0] - terms[1]).double().mean() + (terms[2] - terms[3]).double().mean()) / 2
+    assert abs(float(loss) - float(want)) < 2e-5
+    assert 0.0 < float(loss) < np.log(N)                             # informative pairs: far below the uniform-guess loss
+    # backward at the same shape: local-side gradient rows of the sampled set against the closed form (P recomputed on the CPU)
+    d_img, d_txt, _, _, d_s = H.clip_loss_backward(img, txt, dai, dat, s, off, terms.to(DEV), grad=1.0, gathered=False)
+    pi = torch.softmax(li, 1)
+    pi[torch.arange(64), off + rows] -= 1.0
+    ref = (s / (2 * b)) * pi @ at
+    assert (d_img.cpu()[rows] - ref).abs().max() < 2e-6 + 1e-4 * ref.abs().max()
+
+
 def test_clip_loss_golden_reference_ranks():
     from conftest import golden
     g = golden("cliploss_ws.npz")
