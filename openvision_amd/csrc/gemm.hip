@@ -716,12 +716,25 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist(const GemmArgs 
         char* dst = sbase + boff + p * PIECE_BYTES;
         const ov_bf16* s0 = (p & 1) ? ts.w0 : ts.a0;
         const ov_bf16* s1 = (p & 1) ? ts.w1 : ts.a1;
-        if (p >> 1) {
-            __builtin_amdgcn_global_load_lds((gptr_t)s0, (lptr_t)(dst - 64), 16, 64, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)s1, (lptr_t)(dst + 8192 - 64), 16, 64, 0);
+#ifndef OVHIP_NT_A
+#define OVHIP_NT_A 0          /* experiment: 2 = non-temporal (streaming) cache policy for the A pieces (W keeps the default) */
+#endif
+        if (p & 1) {
+            if (p >> 1) {
+                __builtin_amdgcn_global_load_lds((gptr_t)s0, (lptr_t)(dst - 64), 16, 64, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)s1, (lptr_t)(dst + 8192 - 64), 16, 64, 0);
+            } else {
+                __builtin_amdgcn_global_load_lds((gptr_t)s0, (lptr_t)dst, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)s1, (lptr_t)(dst + 8192), 16, 0, 0);
+            }
         } else {
-            __builtin_amdgcn_global_load_lds((gptr_t)s0, (lptr_t)dst, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)s1, (lptr_t)(dst + 8192), 16, 0, 0);
+            if (p >> 1) {
+                __builtin_amdgcn_global_load_lds((gptr_t)s0, (lptr_t)(dst - 64), 16, 64, OVHIP_NT_A);
+                __builtin_amdgcn_global_load_lds((gptr_t)s1, (lptr_t)(dst + 8192 - 64), 16, 64, OVHIP_NT_A);
+            } else {
+                __builtin_amdgcn_global_load_lds((gptr_t)s0, (lptr_t)dst, 16, 0, OVHIP_NT_A);
+                __builtin_amdgcn_global_load_lds((gptr_t)s1, (lptr_t)(dst + 8192), 16, 0, OVHIP_NT_A);
+            }
         }
     };
     // tile parameters -> LDS block `slot` (lane-linear DMA images): wave 0 the 256 bias values, wave 1 the column sums,

@@ -1,9 +1,9 @@
 """Training-side forward with gradients: the block stacks and the InfoNCE loss are autograd nodes whose
 forward AND backward are the HIP kernels (``ov_tower_forward_saving`` / ``ov_tower_backward``, ``ov_clip_loss`` /
-``ov_clip_loss_backward``).  The light ends around the towers — patch projection, class / positional embeddings, pooling,
-``ln_post`` / ``ln_final``, the output projections and the L2 normalisation (0.2 % of a step's FLOPs) — are ordinary torch
-operations on the device, differentiated by torch autograd; they are plumbing between the two HIP nodes, exactly the modules the
-reference differentiates the same way (open_clip/transformer.py:609-651, model.py:265-315).
+``ov_clip_loss_backward``).  The light ends around the towers run on the HIP operators too: the patch projection and the output
+projections are autograd nodes over ``ov_gemm`` / ``ov_linear_backward``, ``ln_post`` / ``ln_final`` over ``ov_layernorm`` /
+``ov_layernorm_backward`` (open_clip/transformer.py:609-651, model.py:265-315); what is left to torch autograd is data movement and
+element-wise plumbing (class / positional embedding adds, token gather, mean pooling, L2 normalisation) -- no aten GEMM.
 
 Opt-in: the inference entry points of ``openvision_amd.model`` never build a graph; a training loop calls
 
@@ -54,6 +54,50 @@ def _pad_mlp(ts: List[torch.Tensor], mlp: int, mlp_pad: int) -> List[torch.Tenso
     return ts
 
 
+class _Pool:
+    """Grow-only pool of device buffers (saved activations: 19 GB at L/14, B = 256; workspaces): a step takes what it needs in
+    forward and hands it back at the end of backward, so steady-state training allocates nothing per step."""
+
+    def __init__(self):
+        self.free: List[torch.Tensor] = []
+
+    def take(self, nbytes: int, device) -> torch.Tensor:
+        for i, t in enumerate(self.free):
+            if t.device == device and t.numel() >= nbytes:
+                t = self.free.pop(i)
+                t._ovhip_gen += 1              # whoever still holds it from an earlier step can tell it was recycled
+                return t
+        t = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=device)
+        t._ovhip_gen = 0
+        return t
+
+    def give(self, t: torch.Tensor) -> None:
+        self.free.append(t)
+        self.free.sort(key=lambda x: x.numel())
+        del self.free[:-4]                 # keep the four largest
+
+
+def _train_state(transformer):
+    st = getattr(transformer, "_ovhip_train_state", None)
+    if st is None:
+        st = {"sig": None, "keep": None, "pool": _Pool()}
+        object.__setattr__(transformer, "_ovhip_train_state", st)
+    return st
+
+
+def _packed_blocks(transformer, params, mlp: int, mlp_pad: int):
+    """Kernel-layout copies of every block's parameters, rebuilt only when a parameter changed: keyed, as the inference path's
+    cache is, by (data_ptr, _version) of the sources (an optimiser step bumps _version; frozen weights -- gradient ascent on the
+    inputs, ov-gradient-ascent.py -- hit the cache every step).  `model.invalidate_packed()` drops it (writes through .data)."""
+    from .model import _PACK_EPOCH
+    st = _train_state(transformer)
+    sig = (_PACK_EPOCH[0], mlp_pad) + tuple((p.data_ptr(), p._version, p.dtype, p.device) for p in params)
+    if st["sig"] != sig:
+        st["keep"] = [_pad_mlp([_device_copy(p) for p in params[12 * i:12 * i + 12]], mlp, mlp_pad) for i in range(len(params) // 12)]
+        st["sig"] = sig
+    return st["keep"]
+
+
 class _TowerFn(torch.autograd.Function):
     """Transformer.forward (transformer.py:355-366) as one autograd node over all its blocks."""
 
@@ -70,22 +114,23 @@ class _TowerFn(torch.autograd.Function):
         handle = lib.ov_tower_create(C.byref(cfg))
         if not handle:
             raise _lib.OvhipError("ov_tower_create failed")
+        pool = _train_state(transformer)["pool"]
         try:
-            keep = []
-            for i in range(len(blocks)):
-                ts = _pad_mlp([_device_copy(p) for p in params[12 * i:12 * i + 12]], mlp, mlp_pad)
-                keep.append(ts)
+            keep = _packed_blocks(transformer, params, mlp, mlp_pad)
+            for i, ts in enumerate(keep):
                 bw = _lib.BlockWeights(*[C.c_void_p(t.data_ptr()) for t in ts], None, None)
                 check(lib.ov_tower_set_block(handle, i, C.byref(bw)), "ov_tower_set_block")
             xb = x.detach().to(torch.bfloat16).contiguous().clone()
-            saved = torch.empty(lib.ov_tower_saved_bytes(handle, bsz, seq) // 2, dtype=torch.bfloat16, device=x.device)
+            saved = pool.take(lib.ov_tower_saved_bytes(handle, bsz, seq), x.device)
             nbytes = lib.ov_tower_workspace_bytes(handle, bsz, seq)
-            ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=x.device)
+            ws = pool.take(nbytes, x.device)
             check(lib.ov_tower_forward_saving(handle, ptr(xb), ptr(saved), bsz, seq, ptr(ws), nbytes, stream_ptr()),
                   "ov_tower_forward_saving")
+            pool.give(ws)
         finally:
             lib.ov_tower_destroy(handle)
-        ctx.cfg, ctx.keep, ctx.saved, ctx.shape, ctx.mlp = cfg, keep, saved, (bsz, seq, d), mlp
+        ctx.cfg, ctx.keep, ctx.saved, ctx.shape, ctx.mlp, ctx.pool = cfg, keep, saved, (bsz, seq, d), mlp, pool
+        ctx.saved_gen = saved._ovhip_gen
         ctx.x_dtype, ctx.p_dtypes = x.dtype, [p.dtype for p in params]
         return xb.to(x.dtype)
 
@@ -94,6 +139,9 @@ class _TowerFn(torch.autograd.Function):
         lib = _lib.load()
         bsz, seq, d = ctx.shape
         layers = len(ctx.keep)
+        if ctx.saved._ovhip_gen != ctx.saved_gen:
+            raise _lib.OvhipError("training path: the saved activations of this graph were recycled by a later forward; a second "
+                                  "backward over the same graph must come before the next forward of this tower")
         handle = lib.ov_tower_create(C.byref(ctx.cfg))
         try:
             for i, ts in enumerate(ctx.keep):
@@ -103,9 +151,12 @@ class _TowerFn(torch.autograd.Function):
             garr = (_lib.BlockGrads * layers)(*[_lib.BlockGrads(*[C.c_void_p(t.data_ptr()) for t in g]) for g in grads])
             dx = grad_out.detach().to(torch.bfloat16).contiguous().clone()
             nbytes = lib.ov_tower_backward_workspace_bytes(handle, bsz, seq)
-            ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dx.device)
+            ws = ctx.pool.take(nbytes, dx.device)
             check(lib.ov_tower_backward(handle, ptr(ctx.saved), ptr(dx), garr, bsz, seq, ptr(ws), nbytes, stream_ptr()),
                   "ov_tower_backward")
+            ctx.pool.give(ws)
+            if not any(t is ctx.saved for t in ctx.pool.free):
+                ctx.pool.give(ctx.saved)     # ordered on the stream: the next forward's writes come after this backward's reads
         finally:
             lib.ov_tower_destroy(handle)
         mlp = ctx.mlp                                             # drop the (exactly zero) gradients of the MLP padding
@@ -113,6 +164,88 @@ class _TowerFn(torch.autograd.Function):
             gs[8], gs[9], gs[10] = gs[8][:mlp], gs[9][:mlp], gs[10][:, :mlp]
         flat = [g.to(ctx.p_dtypes[12 * i + j]) for i, gs in enumerate(grads) for j, g in enumerate(gs)]
         return (None, dx.view(bsz, seq, d).to(ctx.x_dtype), *flat)
+
+
+def _round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = x W^T (+ b) on ov_gemm, backward on ov_linear_backward: the light-end projections of the towers (patch projection
+    transformer.py:610-612 as a GEMM over patch rows, `@ proj` :645-646, `@ text_projection` model.py:282) -- no aten / hipBLASLt GEMM
+    on the training path.  x [M, K] any float dtype, w [N, K]; K and N are zero-padded to the kernels' 64 granule."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        lib = _lib.load()
+        m, k = x.shape
+        n = w.shape[0]
+        kp, npad = _round_up(k, 64), _round_up(n, 64)
+        xb = torch.zeros(m, kp, dtype=torch.bfloat16, device=x.device)
+        xb[:, :k] = x.detach()
+        wb = torch.zeros(npad, kp, dtype=torch.bfloat16, device=x.device)
+        wb[:n, :k] = w.detach()
+        bb = None
+        if bias is not None:
+            bb = torch.zeros(npad, dtype=torch.float32, device=x.device)
+            bb[:n] = bias.detach().float()
+        out = torch.empty(m, npad, dtype=torch.bfloat16, device=x.device)
+        check(lib.ov_gemm(ptr(xb), kp, ptr(wb), kp, ptr(bb), ptr(out), npad, m, npad, kp, _lib.EPI_BIAS, None, 0, 0, 0, 0, stream_ptr()),
+              "ov_gemm")
+        ctx.save_for_backward(xb, wb)
+        ctx.dims = (m, n, k, kp, npad, bias is not None, x.dtype, w.dtype, bias.dtype if bias is not None else None)
+        return out[:, :n].float()
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        xb, wb = ctx.saved_tensors
+        m, n, k, kp, npad, has_b, xd, wd, bd = ctx.dims
+        dyb = torch.zeros(m, npad, dtype=torch.bfloat16, device=dy.device)
+        dyb[:, :n] = dy.detach()
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dx = torch.empty(m, kp, dtype=torch.bfloat16, device=dy.device) if need_x else None
+        dw = torch.empty(npad, kp, dtype=torch.bfloat16, device=dy.device) if need_w else None
+        db = torch.empty(npad, dtype=torch.float32, device=dy.device) if has_b else None
+        nb = lib.ov_linear_backward_workspace_bytes(m, npad, kp)
+        ws = torch.empty(nb + 256, dtype=torch.uint8, device=dy.device)
+        check(lib.ov_linear_backward(ptr(dyb), npad, ptr(xb), kp, ptr(wb), kp, m, npad, kp, ptr(dx), kp, ptr(dw), kp, ptr(db), ptr(ws), nb,
+                                     stream_ptr()), "ov_linear_backward")
+        return (dx[:, :k].to(xd) if need_x else None, dw[:n, :k].to(wd) if need_w else None, db[:n].to(bd) if has_b else None)
+
+
+class _LayerNormFn(torch.autograd.Function):
+    """LayerNorm (transformer.py:15-30: fp32 statistics) on ov_layernorm / ov_layernorm_backward: ln_post on the pooled rows, ln_final
+    on the text tokens."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        lib = _lib.load()
+        d = x.shape[-1]
+        xb = x.detach().to(torch.bfloat16).contiguous().view(-1, d)
+        g, b = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        y = torch.empty(xb.shape, dtype=torch.float32, device=x.device)
+        check(lib.ov_layernorm(ptr(xb), _lib.OV_BF16, d, ptr(g), ptr(b), ptr(y), _lib.OV_F32, d, xb.shape[0], d, float(eps), stream_ptr()),
+              "ov_layernorm")
+        ctx.save_for_backward(xb, g)
+        ctx.meta = (x.shape, float(eps), x.dtype, weight.dtype, bias.dtype)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        xb, g = ctx.saved_tensors
+        shape, eps, xd, wd, bd = ctx.meta
+        rows, d = xb.shape
+        dyb = dy.detach().to(torch.bfloat16).contiguous().view(rows, d)
+        dx = torch.empty_like(xb)
+        dg = torch.empty(d, dtype=torch.float32, device=dy.device)
+        db = torch.empty(d, dtype=torch.float32, device=dy.device)
+        nb = lib.ov_layernorm_backward_workspace_bytes(rows, d)
+        ws = torch.empty(nb + 256, dtype=torch.uint8, device=dy.device)
+        check(lib.ov_layernorm_backward(ptr(xb), d, ptr(g), ptr(dyb), d, None, 0, ptr(dx), d, ptr(dg), ptr(db), rows, d, eps, ptr(ws), nb,
+                                        stream_ptr()), "ov_layernorm_backward")
+        return dx.view(shape).to(xd), dg.to(wd), db.to(bd), None
 
 
 def tower_forward(transformer, x: torch.Tensor) -> torch.Tensor:
@@ -135,37 +268,54 @@ def encode_image(model, image: torch.Tensor, normalize: bool = True) -> torch.Te
     # (MIOpen's fp32 convolution path costs tens of ms per step at this shape)
     bsz, _, hh, ww = image.shape
     gh, gw = hh // p, ww // p
-    patches = image.float().reshape(bsz, 3, gh, p, gw, p).permute(0, 2, 4, 1, 3, 5).reshape(bsz, gh * gw, 3 * p * p)
-    x = patches @ w.float().reshape(w.shape[0], -1).t()
+    patches = image.reshape(bsz, 3, gh, p, gw, p).permute(0, 2, 4, 1, 3, 5).reshape(bsz * gh * gw, 3 * p * p)
+    x = _LinearFn.apply(patches, w.reshape(w.shape[0], -1), None).view(bsz, gh * gw, -1)
     cls = v.class_embedding.float().expand(x.shape[0], 1, -1)
     x = torch.cat([cls, x], dim=1) + v.positional_embedding.float()                            # :615-617
     x = tower_forward(v.transformer, x)
     if v.final_ln_after_pool:
         pooled = x[:, 1:].mean(dim=1) if v.pool_type == "avg" else x[:, 0]
-        pooled = F.layer_norm(pooled, (pooled.shape[-1],), v.ln_post.weight.float(), v.ln_post.bias.float(), v.ln_post.eps)
+        pooled = _LayerNormFn.apply(pooled, v.ln_post.weight, v.ln_post.bias, v.ln_post.eps)
     else:
-        xx = F.layer_norm(x, (x.shape[-1],), v.ln_post.weight.float(), v.ln_post.bias.float(), v.ln_post.eps)
+        xx = _LayerNormFn.apply(x, v.ln_post.weight, v.ln_post.bias, v.ln_post.eps)
         pooled = xx[:, 1:].mean(dim=1) if v.pool_type == "avg" else xx[:, 0]
-    out = pooled @ v.proj.float()
+    out = _LinearFn.apply(pooled, v.proj.t(), None)
     return F.normalize(out, dim=-1) if normalize else out
 
 
-def encode_text(model, text: torch.Tensor, normalize: bool = True) -> torch.Tensor:
-    """CLIP.encode_text (model.py:269-284) with gradients: no mask, ln_final on all tokens, pool per text_pool_type."""
-    x = F.embedding(text, model.token_embedding.weight.float()) + model.positional_embedding.float()
+def encode_text_embeddings(model, x: torch.Tensor, normalize: bool = True, pool_index=None) -> torch.Tensor:
+    """The text tower from token EMBEDDINGS x [B, T, width] (before the positional embedding), with gradients to x: the entry of
+    ov-gradient-ascent.py:102-127, which feeds `soft_one_hot @ token_embedding.weight` instead of token ids.  `pool_index` (int64 [B])
+    selects the pooled position for text_pool_type 'argmax' (ids are not available here)."""
+    x = x.float() + model.positional_embedding.float()[: x.shape[1]]
     x = tower_forward(model.transformer, x)
-    x = F.layer_norm(x, (x.shape[-1],), model.ln_final.weight.float(), model.ln_final.bias.float(), model.ln_final.eps)
+    x = _LayerNormFn.apply(x, model.ln_final.weight, model.ln_final.bias, model.ln_final.eps)
     pool = getattr(model, "text_pool_type", "last")
     if pool == "last":
         pooled = x[:, -1]
     elif pool == "first":
         pooled = x[:, 0]
     elif pool == "argmax":
-        pooled = x[torch.arange(x.shape[0], device=x.device), text.argmax(dim=-1)]
+        if pool_index is None:
+            raise _lib.OvhipError("training path: text pool type 'argmax' needs pool_index when embeddings are given")
+        pooled = x[torch.arange(x.shape[0], device=x.device), pool_index]
     else:
         raise _lib.OvhipError(f"training path: text pool type {pool!r} is not supported")
-    out = pooled @ model.text_projection.float()
+    out = _LinearFn.apply(pooled, model.text_projection.t(), None)
     return F.normalize(out, dim=-1) if normalize else out
+
+
+def encode_text(model, text: torch.Tensor, normalize: bool = True) -> torch.Tensor:
+    """CLIP.encode_text (model.py:269-284) with gradients: no mask, ln_final on all tokens, pool per text_pool_type.  `text`: int64
+    token ids [B, T], or a float [B, T, vocab] matrix of (soft) one-hot rows (ov-gradient-ascent.py:105: `text @ token_embedding.weight`,
+    gradients flow to the rows)."""
+    if text.is_floating_point():
+        if text.dim() != 3 or text.shape[-1] != model.token_embedding.weight.shape[0]:
+            raise ValueError("soft tokens must be [B, T, vocab_size]")
+        return encode_text_embeddings(model, text.float() @ model.token_embedding.weight.float(), normalize,
+                                      text.argmax(dim=-1).argmax(dim=-1))
+    x = F.embedding(text, model.token_embedding.weight.float())
+    return encode_text_embeddings(model, x, normalize, text.argmax(dim=-1))
 
 
 def clip_forward(model, image: torch.Tensor, text: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:

@@ -550,6 +550,49 @@ def test_training_step_gradients_tiny(tiny):
     assert not f.requires_grad and one_minus_cos(f.cpu(), fi.detach()) < 1e-3
 
 
+def test_training_soft_token_entry_gradient(tiny):
+    """ov-gradient-ascent.py:102-127,241-259: the text tower fed with `soft_one_hot @ token_embedding.weight`, differentiated w.r.t. the
+    soft rows (weights frozen: the packed-weight cache of the training path is hit on the second call).  Reference = torch autograd
+    through the oracle's block stack on the CPU."""
+    from oracle import clip_ref as R
+    from openvision_amd import training
+    cfg = preset("vit-tiny-patch16-160")
+    sd = synth.make_state_dict(cfg)
+    tcfg = cfg["text_cfg"]
+    g = torch.Generator().manual_seed(3)
+    V, T = tcfg["vocab_size"], tcfg["context_length"]
+    ids = synth.make_captions(3, seed=5)
+    soft0 = torch.nn.functional.one_hot(ids, V).float() * 0.9 + torch.rand(3, T, V, generator=g) * (0.1 / V)
+    target = torch.nn.functional.normalize(torch.randn(3, cfg["embed_dim"], generator=g), dim=-1)
+    # oracle
+    sr = soft0.clone().requires_grad_(True)
+    x = sr @ sd["token_embedding.weight"] + sd["positional_embedding"]
+    x = R.block_stack(x, sd, "transformer.", tcfg["layers"], tcfg["heads"], True)
+    f = R.layer_norm(x, sd["ln_final.weight"], sd["ln_final.bias"])[:, -1] @ sd["text_projection"]
+    ref_loss = -(torch.nn.functional.normalize(f, dim=-1) * target).sum(-1).mean()
+    ref_loss.backward()
+    # product (two calls: the second one must reuse the packed weights)
+    for p in tiny.parameters():
+        p.requires_grad_(False)
+    try:
+        for _ in range(2):
+            sp = soft0.clone().to(DEV).requires_grad_(True)
+            tf = training.encode_text(tiny, sp, normalize=True)
+            loss = -(tf * target.to(DEV)).sum(-1).mean()
+            loss.backward()
+        st = tiny.transformer._ovhip_train_state
+        sig0 = st["sig"]
+        training.encode_text(tiny, sp.detach(), normalize=True)
+        assert st["sig"] is sig0                                   # cache hit: nothing re-packed
+    finally:
+        for p in tiny.parameters():
+            p.requires_grad_(True)
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) < 2e-2
+    gp, gr = sp.grad.float().cpu(), sr.grad
+    cos = float((gp * gr).sum() / (gp.norm() * gr.norm()))
+    assert cos > 0.98 and abs(float(gp.norm()) - float(gr.norm())) < 0.08 * float(gr.norm()), (cos, float(gp.norm()), float(gr.norm()))
+
+
 def test_training_loss_decreases_tiny(tiny):
     """A few SGD steps on one fixed batch through the HIP forward/backward: the loss must go down steadily."""
     from openvision_amd import training

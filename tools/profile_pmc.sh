@@ -1,6 +1,7 @@
 #!/bin/bash
 # Run ON the GPU box (via gpurun) from the repo root: MFMA-busy / LDS-conflict counters of the default bench (own passes,
-# kernel-trace only, as the pool requires).  Post-process with tools/collect_pmc.py.
+# kernel-trace only, as the pool requires).  The per-kernel sums are read from the counter_collection.csv files by hand
+# into profiles/rNN_pmc.json (no post-processing script).
 set -e
 OUT=$PWD/gpurun_out
 mkdir -p $OUT
