@@ -284,6 +284,18 @@ int ov_debug_gemm_stamps(unsigned long long* buf, int slots);
 /* Diagnostics: per-wave epilogue timeline [workgroup][slots][8 waves][8] (NULL = off; `slots` as given to ov_debug_gemm_stamps). */
 int ov_debug_gemm_wave_stamps(unsigned long long* wbuf);
 
+/* ---- parameter update of the training step.  The reference's trainer chains optax transforms
+ * (src/optim/build_optax.py:272-278, applied at src/main_clip.py:480-483): clip_by_global_norm -> scale_by_adam(b1, b2,
+ * mu_dtype=bfloat16) -> add_decayed_weights(wd) -> scale(lr) -> scale_by_schedule -> scale(-1).  One fused pass over flat fp32
+ * buffers: p -= lr * ( mu_hat / (sqrt(nu_hat) + eps) + wd * p ), mu kept in bf16, nu in fp32, bias correction by `step` (>= 1).
+ * grad_scale multiplies every gradient first (1 / world_size after a SUM all-reduce); gnorm_sq (device scalar from ov_sumsq over the
+ * same unscaled gradients, NULL = off) enables global-norm clipping at clip_norm without a host round trip.  HBM-bound: 24 B / element. */
+int ov_adamw_step(float* p, const float* g, ov_bf16* mu, float* nu, int64_t n, float lr, float b1, float b2, float eps, float wd,
+                  int step, float grad_scale, const float* gnorm_sq, float clip_norm, ov_stream_t stream);
+/* out[0] = (accumulate ? out[0] : 0) + sum_i g[i]^2   (two-stage fixed-order reduction: deterministic). */
+size_t ov_sumsq_workspace_bytes(void);
+int ov_sumsq(const float* g, int64_t n, float* out, int accumulate, void* workspace, size_t workspace_bytes, ov_stream_t stream);
+
 /* ---- tower level (the resblock loop and the two encoders) --------------------------------------- */
 
 typedef struct ov_tower ov_tower;     /* opaque host object holding BORROWED device weight pointers */

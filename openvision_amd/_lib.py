@@ -117,6 +117,10 @@ SIGNATURES = {
     "ov_tower_saved_bytes": (c_size_t, [c_void_p, c_int, c_int]),
     "ov_clip_loss_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p,
                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "ov_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float, c_int, c_float,
+                              c_void_p, c_float, c_void_p]),
+    "ov_sumsq_workspace_bytes": (c_size_t, []),
+    "ov_sumsq": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "ov_profile_enable": (c_int, [C.c_uint, c_int]),
     "ov_profile_read": (c_int, [c_int, C.POINTER(C.c_double), C.POINTER(c_int), C.POINTER(C.c_double)]),
     "ov_debug_gemm_stamps": (c_int, [c_void_p, c_int]),

@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 OUT = os.path.join(PKG, "libovhip.so")
-SOURCES = ["gemm.hip", "gemm_fp8.hip", "quant.hip", "layernorm.hip", "attention.hip", "attention_bwd.hip", "embed.hip", "loss.hip", "eval.hip", "preprocess.hip", "backward.hip", "tower.hip"]
+SOURCES = ["gemm.hip", "gemm_fp8.hip", "quant.hip", "layernorm.hip", "attention.hip", "attention_bwd.hip", "embed.hip", "loss.hip", "eval.hip", "preprocess.hip", "backward.hip", "optim.hip", "tower.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 
 

@@ -92,6 +92,36 @@ def invalidate_packed() -> None:
     _PACK_EPOCH[0] += 1
 
 
+class _GraphCache:
+    """hipGraph replay of a launch-bound encode call (batch-1 zero-shot path: ~170 kernel launches per image whose host-side
+    launch cost exceeds their device time).  The launch sequence is captured ONCE per (shape, dtype, flags) on a capture stream
+    (every kernel of libovhip goes to the current torch stream, so torch.cuda.graph records them as graph kernel nodes), then
+    replayed: copy the input into the captured call's static input, one hipGraphLaunch, clone the static output.  Weights are
+    baked in as pointers: a parameter change (pack epoch / _version) drops the graphs."""
+
+    def __init__(self):
+        self.graphs = {}
+        self.sig = None
+
+    def run(self, key, weights_sig, x: torch.Tensor, fn):
+        if self.sig != weights_sig:
+            self.graphs.clear()
+            self.sig = weights_sig
+        ent = self.graphs.get(key)
+        if ent is None:
+            static_in = x.clone()
+            fn(static_in)                                   # warm-up outside capture: packs weights, sizes workspaces, sets attributes
+            torch.cuda.current_stream(x.device).synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                static_out = fn(static_in)
+            ent = self.graphs[key] = (g, static_in, static_out)
+        g, static_in, static_out = ent
+        static_in.copy_(x)
+        g.replay()
+        return static_out.clone()
+
+
 def _pack_matrix(w: torch.Tensor, n_pad: int, k_pad: int) -> torch.Tensor:
     """[N,K] any float dtype -> zero-padded bf16 [n_pad, k_pad], contiguous."""
     n, k = w.shape
@@ -625,6 +655,8 @@ class CLIP(nn.Module):
         self._ws = _Workspace()
         self._err = None
         self._side_stream = None
+        self._graphs = _GraphCache()
+        self.graph_max_batch = int(os.environ.get("OVHIP_GRAPH_MAX_BATCH", "0"))    # 0 = off; see use_graphs()
         self.overlap_towers = os.environ.get("OVHIP_OVERLAP_TOWERS", "0") == "1"   # measured gain < 1 %: opt-in
         if cast_dtype is not None and cast_dtype not in (torch.float32, torch.bfloat16):
             raise NotImplementedError("cast_dtype must be float32 or bfloat16")
@@ -655,15 +687,34 @@ class CLIP(nn.Module):
         self.visual.transformer.freeze_fp8_scales()
         self.transformer.freeze_fp8_scales()
 
+    def use_graphs(self, max_batch: int = 8) -> None:
+        """Replay encode_image / encode_text calls of at most `max_batch` rows as captured hipGraphs (0 turns it off).  For the
+        launch-bound small-batch path (ov-zero-shot-test.py:167-195 encodes one image at a time); results are bitwise those of the
+        plain launches."""
+        self.graph_max_batch = int(max_batch)
+
+    def _weights_sig(self):
+        return (_PACK_EPOCH[0],) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+
     def encode_image(self, image: torch.Tensor, normalize: bool = False) -> torch.Tensor:
         """model.py:265-267.  Returns fp32 [B, embed_dim]."""
+        if 0 < image.shape[0] <= self.graph_max_batch and image.is_cuda and not torch.cuda.is_current_stream_capturing():
+            self.visual._check_image(image)
+            x = image.detach()
+            x = x.contiguous() if x.dtype in (torch.float32, torch.bfloat16) else x.float().contiguous()
+            return self._graphs.run(("img", tuple(x.shape), x.dtype, bool(normalize), self.visual.transformer._cache.precision),
+                                    self._weights_sig(), x, lambda t: self.visual._encode(t, normalize))
         return self.visual._encode(image, normalize)
 
-    def encode_text(self, text: torch.Tensor, normalize: bool = False) -> torch.Tensor:
+    def encode_text(self, text: torch.Tensor, normalize: bool = False, _graphed: bool = False) -> torch.Tensor:
         """model.py:269-284.  ``text`` int64 [B, context_length] (the whole pos-emb is added: model.py:274)."""
         _require_cuda(text, "encode_text")
         if text.dim() != 2 or text.shape[1] != self.context_length:
             raise ValueError(f"expected tokens [B,{self.context_length}], got {tuple(text.shape)}")
+        if 0 < text.shape[0] <= self.graph_max_batch and not torch.cuda.is_current_stream_capturing() and not _graphed:
+            t = text.detach().to(torch.int64).contiguous()
+            return self._graphs.run(("txt", tuple(t.shape), bool(normalize), self.transformer._cache.precision), self._weights_sig(),
+                                    t, lambda z: self.encode_text(z, normalize, _graphed=True))
         lib = _lib.load()
         head, _keep = self._text_head()
         tower = self.transformer.tower()

@@ -321,3 +321,120 @@ def encode_text(model, text: torch.Tensor, normalize: bool = True) -> torch.Tens
 def clip_forward(model, image: torch.Tensor, text: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """CLIP.forward (model.py:295-315) with gradients: (image_features, text_features, logit_scale.exp())."""
     return encode_image(model, image, True), encode_text(model, text, True), model.logit_scale.exp()
+
+
+# --------------------------------------------------------------------------------------------------------------------------
+# parameter update + data-parallel gradient exchange: what closes the training step (src/main_clip.py:480-483)
+# --------------------------------------------------------------------------------------------------------------------------
+def default_decay_filter(name: str, p: torch.Tensor) -> bool:
+    """The reference decays '.*/kernel$' only (build_optax.py:259: Dense / Conv kernels): here the 2-D (and conv) weight matrices;
+    biases, LayerNorm parameters, class / positional / token embeddings and the logit scale are not decayed."""
+    if name.endswith("token_embedding.weight") or "positional_embedding" in name or name.endswith("class_embedding"):
+        return False
+    return p.dim() >= 2
+
+
+class FusedAdamW:
+    """The reference trainer's update (optax chain of src/optim/build_optax.py:272-278 with config.optax = scale_by_adam(b1=0.9,
+    b2=0.95, mu_dtype=bfloat16), decoupled weight decay scaled by the learning rate, optional global-norm clipping) as ONE HIP launch
+    per parameter group over flat buffers (``ov_adamw_step``), plus the data-parallel gradient exchange.
+
+    Parameters are re-homed into two flat fp32 buffers (decayed / not decayed) and their ``.grad`` into matching flat gradient
+    buffers, so the all-reduce works on a few large contiguous buckets (xGMI rings are per-link bound: few, large messages) and the
+    update is two launches.  fp32 parameters only.  After ``step()`` the packed bf16 copies of the model are invalidated (the
+    kernel writes parameters without touching ``_version``)."""
+
+    def __init__(self, model, lr: float, b1: float = 0.9, b2: float = 0.95, eps: float = 1e-8, wd: float = 0.2,
+                 clip_norm: float = None, decay_filter=default_decay_filter, bucket_bytes: int = 256 << 20):
+        self.model, self.lr, self.b1, self.b2, self.eps, self.wd, self.clip_norm = model, lr, b1, b2, eps, wd, clip_norm
+        self.bucket_bytes = int(bucket_bytes)
+        self.t = 0
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        if not named:
+            raise ValueError("no trainable parameters")
+        dev = named[0][1].device          # CPU tensors: buffers and the gradient exchange work (gloo tests); step() refuses
+        self.groups = []
+        for decayed in (True, False):
+            ps = [(n, p) for n, p in named if bool(decay_filter(n, p)) == decayed]
+            if not ps:
+                continue
+            if any(p.dtype != torch.float32 for _, p in ps):
+                raise _lib.OvhipError("FusedAdamW: fp32 master parameters only")
+            offs, total = [], 0
+            for _, p in ps:
+                offs.append(total)
+                total += (p.numel() + 3) // 4 * 4                       # every tensor starts 16-byte aligned
+            flat = torch.zeros(total, dtype=torch.float32, device=dev)
+            grad = torch.zeros(total, dtype=torch.float32, device=dev)
+            with torch.no_grad():
+                for (_, p), o in zip(ps, offs):
+                    flat[o:o + p.numel()].copy_(p.detach().reshape(-1))
+                    p.data = flat[o:o + p.numel()].view(p.shape)
+                    p.grad = grad[o:o + p.numel()].view(p.shape)
+            self.groups.append(dict(params=ps, offs=offs, flat=flat, grad=grad, wd=wd if decayed else 0.0,
+                                    mu=torch.zeros(total, dtype=torch.bfloat16, device=dev),
+                                    nu=torch.zeros(total, dtype=torch.float32, device=dev)))
+        self._gn = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._ws = torch.empty(4096 + 256, dtype=torch.uint8, device=dev)            # >= ov_sumsq_workspace_bytes()
+        from .model import invalidate_packed
+        invalidate_packed()
+
+    def zero_grad(self) -> None:
+        """Zero the flat gradient buffers; ``.grad`` stays a view of them (set_to_none would detach the views)."""
+        for g in self.groups:
+            g["grad"].zero_()
+            for (_, p), o in zip(g["params"], g["offs"]):
+                want = g["grad"][o:o + p.numel()]
+                if p.grad is None or p.grad.data_ptr() != want.data_ptr():
+                    p.grad = want.view(p.shape)
+
+    def _collect(self) -> None:
+        """A ``.grad`` that autograd replaced instead of accumulating in place is copied back into its flat slot."""
+        for g in self.groups:
+            for (_, p), o in zip(g["params"], g["offs"]):
+                want = g["grad"][o:o + p.numel()]
+                if p.grad is not None and p.grad.data_ptr() != want.data_ptr():
+                    want.copy_(p.grad.detach().reshape(-1).float())
+                    p.grad = want.view(p.shape)
+
+    def buckets(self):
+        """The flat gradient buffers cut into contiguous chunks of at most ``bucket_bytes``."""
+        per = max(1, self.bucket_bytes // 4)
+        for g in self.groups:
+            n = g["grad"].numel()
+            for s in range(0, n, per):
+                yield g["grad"][s:min(n, s + per)]
+
+    def all_reduce_gradients(self, world_size: int, group=None) -> float:
+        """SUM all-reduce of every bucket (RCCL when the backend is 'nccl'), all issued before any is waited for; returns the factor
+        (1 / world_size) that ``step(grad_scale=...)`` folds into the update instead of a separate averaging pass."""
+        import torch.distributed as dist
+        self._collect()
+        if world_size > 1:
+            works = [dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group, async_op=True) for b in self.buckets()]
+            for w in works:
+                w.wait()
+        return 1.0 / world_size
+
+    def step(self, lr: float = None, grad_scale: float = 1.0) -> None:
+        """One update at learning rate ``lr`` (default: the constructor's; the caller evaluates its schedule on the host)."""
+        if self._gn.device.type != "cuda":
+            raise _lib.OvhipError("FusedAdamW.step: parameters must live on an MI355X device (no CPU fallback)")
+        lib = _lib.load()
+        if self._ws.numel() < lib.ov_sumsq_workspace_bytes():
+            self._ws = torch.empty(lib.ov_sumsq_workspace_bytes() + 256, dtype=torch.uint8, device=self._gn.device)
+        self._collect()
+        self.t += 1
+        lr = self.lr if lr is None else lr
+        gn = None
+        if self.clip_norm is not None:
+            for i, g in enumerate(self.groups):
+                check(lib.ov_sumsq(ptr(g["grad"]), g["grad"].numel(), ptr(self._gn), int(i > 0), ptr(self._ws), self._ws.numel(),
+                                   stream_ptr()), "ov_sumsq")
+            gn = self._gn
+        for g in self.groups:
+            check(lib.ov_adamw_step(ptr(g["flat"]), ptr(g["grad"]), ptr(g["mu"]), ptr(g["nu"]), g["flat"].numel(), float(lr), self.b1,
+                                    self.b2, self.eps, float(g["wd"]), self.t, float(grad_scale), ptr(gn) if gn is not None else None,
+                                    float(self.clip_norm or 0.0), stream_ptr()), "ov_adamw_step")
+        from .model import invalidate_packed
+        invalidate_packed()

@@ -78,6 +78,7 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     else:
         from .checkpoint import from_pretrained
         model, pp = from_pretrained(a.use_model, device="cuda:0")     # .bin (weights_only) or safetensors, wrappers unwrapped
+    model.use_graphs(8)          # one image per encode call: ~170 launches each, replayed as one hipGraph
     print(describe(model))
     names, imgs = load_images(a.image_dir, model_cfg["vision_cfg"]["image_size"], pp["mean"], pp["std"])
     if bool(a.tokens) == bool(a.prompts):

@@ -68,6 +68,9 @@ def test_argument_validation_of_the_widening_entry_points():
     assert lib.ov_gelu_backward(None, 8, None, 8, None, 8, None, 0, 1, 8, 0, None) == -1
     assert lib.ov_block_backward(None, None, None, None, None, None, None, 1, 8, None, 0, None) == -1
     assert lib.ov_tower_saved_bytes(None, 1, 8) == 0
+    # parameter update: nulls / bad hyper-parameters are status codes
+    assert lib.ov_adamw_step(None, None, None, None, 16, 1e-3, 0.9, 0.95, 1e-8, 0.0, 1, 1.0, None, 0.0, None) == -1
+    assert lib.ov_sumsq(None, 16, None, 0, None, 0, None) == -1 and lib.ov_sumsq_workspace_bytes() >= 1024
     assert lib.ov_block_backward_workspace_bytes(None, 1, 8) == 0
     assert lib.ov_attention_backward(None, 192, None, 64, None, 64, None, 192, 1, 8, 1, 64, 0.125, None, 0, None) == -1
     assert lib.ov_attention_backward_workspace_bytes(2, 257, 16, 64) == 0 and lib.ov_attention_backward_workspace_bytes(2, 2305, 6, 64) >= 2 * 2 * 6 * 2305 * 4

@@ -58,3 +58,57 @@ def test_gather_requires_process_group():
         gather_features(torch.zeros(2, 8), torch.zeros(2, 8), world_size=2)
     a, b = gather_features(torch.ones(2, 8), torch.zeros(2, 8), world_size=1)
     assert a.shape == (2, 8)
+
+
+def _grad_worker(rank, ws, store, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    dist.init_process_group("gloo", init_method=f"file://{store}", rank=rank, world_size=ws)
+    from openvision_amd import preset, synth, training
+    from openvision_amd.model import create_model
+    from openvision_amd._lib import OvhipError
+    cfg = preset("vit-tiny-patch16-160")
+    m = create_model(cfg, state_dict=synth.make_state_dict(cfg))
+    opt = training.FusedAdamW(m, lr=1e-3, bucket_bytes=1 << 20)             # many buckets: 1 MiB each
+    nb = sum(1 for _ in opt.buckets())
+    g = torch.Generator().manual_seed(100 + rank)
+    for p in m.parameters():
+        p.grad.copy_(torch.randn(p.shape, generator=g))                     # in place: .grad stays a view of the flat buffer
+    m.logit_scale.grad = torch.full((), 3.0 + rank)                         # replaced, not accumulated: _collect must copy it back
+    scale = opt.all_reduce_gradients(ws)
+    gsum = {n: p.grad.clone() for n, p in m.named_parameters()}
+    try:
+        opt.step()
+        refused = False
+    except OvhipError:
+        refused = True
+    q.put((rank, nb, scale, refused, {k: v.numpy() for k, v in gsum.items()} if rank == 0 else None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_gradient_all_reduce_world_size_2():
+    """training.FusedAdamW.all_reduce_gradients over gloo at world_size 2: every bucket of the flat gradient buffers is summed across
+    ranks (the reference averages with the 1/world_size factor, returned for the update kernel), a replaced .grad is folded back in,
+    and the HIP update refuses CPU tensors."""
+    ws = 2
+    ctx = mp.get_context("spawn")
+    with tempfile.TemporaryDirectory() as d:
+        q = ctx.Queue()
+        ps = [ctx.Process(target=_grad_worker, args=(r, ws, os.path.join(d, "store"), q)) for r in range(ws)]
+        [p.start() for p in ps]
+        res = sorted((q.get(timeout=300) for _ in range(ws)), key=lambda r: r[0])
+        [p.join(60) for p in ps]
+    assert all(r[1] > 5 and r[2] == 0.5 and r[3] for r in res)
+    got = res[0][4]
+    from openvision_amd import preset, synth
+    from openvision_amd.model import create_model
+    m = create_model(preset("vit-tiny-patch16-160"))
+    want = {}
+    for rank in range(ws):
+        g = torch.Generator().manual_seed(100 + rank)
+        for n, p in m.named_parameters():
+            want[n] = want.get(n, 0) + torch.randn(p.shape, generator=g)
+    for n in want:
+        ref = want[n].numpy() if n != "logit_scale" else np.float32(3.0 + 4.0)
+        np.testing.assert_allclose(got[n], ref, rtol=1e-6, atol=1e-6, err_msg=n)

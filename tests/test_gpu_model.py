@@ -773,3 +773,86 @@ def test_rccl_branch_of_the_loss_at_world_size_1():
         np.testing.assert_allclose(gi, gi0, atol=2e-7, err_msg=name)
         np.testing.assert_allclose(gt, gt0, atol=2e-7, err_msg=name)
         assert abs(gs - gs0) < 1e-6, name
+
+
+def test_hipgraph_replay_of_small_batch_encode_is_bitwise(tiny):
+    """CLIP.use_graphs: the batch-1 path of ov-zero-shot-test.py:167-195 as a captured hipGraph -- results bit for bit those of the
+    plain launches, for new inputs (the graph is replayed, not re-captured) and again after a weight change (graphs dropped)."""
+    img = synth.make_images(3, 160, seed=71).to(DEV)
+    tok = synth.make_captions(5, seed=71).to(DEV)
+    want_i = [tiny.encode_image(img[i:i + 1], normalize=True) for i in range(3)]
+    want_t = tiny.encode_text(tok, normalize=True)
+    tiny.use_graphs(8)
+    try:
+        got_i = [tiny.encode_image(img[i:i + 1], normalize=True) for i in range(3)]
+        assert len(tiny._graphs.graphs) == 1                       # one capture, three replays
+        got_t = tiny.encode_text(tok, normalize=True)
+        for a, b in zip(want_i, got_i):
+            assert torch.equal(a, b)
+        assert torch.equal(want_t, got_t)
+        assert torch.equal(tiny.encode_text(tok[:2], normalize=True), want_t[:2])     # another shape: another graph
+        with torch.no_grad():
+            tiny.visual.ln_post.bias.add_(0.25)
+        changed = tiny.encode_image(img[0:1], normalize=True)      # weights changed: re-captured, not stale
+        tiny.use_graphs(0)
+        assert torch.equal(changed, tiny.encode_image(img[0:1], normalize=True)) and not torch.equal(changed, want_i[0])
+    finally:
+        tiny.use_graphs(0)
+        with torch.no_grad():
+            tiny.visual.ln_post.bias.sub_(0.25)
+
+
+def test_fused_adamw_matches_the_optax_restatement(tiny):
+    """training.FusedAdamW (ov_adamw_step / ov_sumsq) over three steps with clipping and a 1/world_size gradient scale against
+    oracle/optim_ref.py (numpy restatement of the reference trainer's optax chain, build_optax.py:272-278: parity unpinned vs optax
+    itself, which is not installed).  Also: parameters stay the model's parameters (views of the flat buffers), the packed bf16
+    copies follow the update, weight decay only touches the weight matrices."""
+    from oracle import optim_ref as O
+    from openvision_amd import training
+    cfg = preset("vit-tiny-patch16-160")
+    m = create_model(cfg, device=DEV, state_dict=synth.make_state_dict(cfg))
+    before = m.encode_image(synth.make_images(2, 160, seed=3).to(DEV))
+    opt = training.FusedAdamW(m, lr=1e-3, wd=0.2, clip_norm=1.0)
+    assert len(opt.groups) == 2 and opt.groups[0]["wd"] == 0.2 and opt.groups[1]["wd"] == 0.0
+    names = [n for n, _ in opt.groups[0]["params"]]
+    assert "visual.proj" in names and "visual.conv1.weight" in names and "visual.ln_post.weight" not in names and "logit_scale" not in names
+    ref = [dict(p=g["flat"].cpu().numpy().copy(), mu=np.zeros(g["flat"].numel(), np.float32), nu=np.zeros(g["flat"].numel(), np.float32),
+                wd=g["wd"]) for g in opt.groups]
+    gen = torch.Generator().manual_seed(11)
+    for step in range(1, 4):
+        opt.zero_grad()
+        grads = []
+        for g in opt.groups:
+            gr = torch.randn(g["grad"].numel(), generator=gen) * (0.05 * step)
+            g["grad"].copy_(gr.to(DEV))
+            grads.append(gr.numpy())
+        scale = 0.5                                                  # as after a SUM all-reduce over two ranks
+        gnorm = np.sqrt(sum((gr.astype(np.float64) ** 2).sum() for gr in grads)) * scale
+        opt.step(lr=1e-3 * step, grad_scale=scale)
+        for r, gr in zip(ref, grads):
+            r["p"], r["mu"], r["nu"] = O.adamw_step(r["p"], gr, r["mu"], r["nu"], step, 1e-3 * step, 0.9, 0.95, 1e-8, r["wd"], scale, 1.0, gnorm)
+    for g, r in zip(opt.groups, ref):
+        # the clip factor comes from an fp32 device reduction (the oracle sums in fp64): it differs in the last bit, which flips the
+        # bf16 rounding of the first moment for ~1e-4 of the elements (one bf16 ulp of mu = 2^-8 of that element's update)
+        got_p = g["flat"].cpu().numpy()
+        bad = ~np.isclose(got_p, r["p"], rtol=2e-5, atol=2e-6)
+        assert bad.mean() < 1e-3 and np.abs(got_p - r["p"]).max() < 3e-3 * 2 ** -6, (bad.mean(), np.abs(got_p - r["p"]).max())
+        np.testing.assert_allclose(g["nu"].cpu().numpy(), r["nu"], rtol=2e-5, atol=1e-12)
+        mu = g["mu"].float().cpu().numpy()
+        assert np.mean(mu != r["mu"]) < 1e-3 and np.abs(mu - r["mu"]).max() <= np.abs(r["mu"]).max() * 2 ** -7   # bf16: ulp flips only
+    p = dict(m.named_parameters())["visual.proj"]
+    assert p.data_ptr() >= opt.groups[0]["flat"].data_ptr() and p.is_cuda              # still the module's parameter, re-homed
+    after = m.encode_image(synth.make_images(2, 160, seed=3).to(DEV))
+    assert not torch.equal(before, after)                                              # packed copies were invalidated by step()
+    # end to end: two optimiser steps on a real loss go down
+    from openvision_amd.loss import ClipLoss
+    img, tok = synth.make_images(8, 160, seed=31).to(DEV), synth.make_captions(8, seed=31).to(DEV)
+    opt2 = training.FusedAdamW(m, lr=2e-4, wd=0.0)
+    losses = []
+    for _ in range(4):
+        opt2.zero_grad()
+        loss = ClipLoss()(*training.clip_forward(m, img, tok))
+        loss.backward()
+        opt2.step(grad_scale=opt2.all_reduce_gradients(1))
+        losses.append(float(loss.detach()))
+    assert losses[-1] < losses[0], losses

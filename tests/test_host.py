@@ -133,3 +133,24 @@ def test_invalidate_packed_after_dot_data_writes():
     m.load_state_dict(synth.make_state_dict(cfg, seed=1))
     assert m.visual.ln_post.packed() is not ln
     m.invalidate_packed()
+
+
+def test_optimizer_oracle_self_consistency_and_decay_filter():
+    """oracle/optim_ref.py on a hand case (first step of Adam with bias correction: the direction is sign(g) / (1 + eps-ish)), bf16
+    rounding of the first moment, clipping; and the decay mask of training.default_decay_filter on the real parameter names."""
+    from oracle import optim_ref as O
+    from openvision_amd import training
+    p, g = np.array([1.0, -2.0, 0.5], np.float32), np.array([0.1, -0.2, 0.0], np.float32)
+    p1, mu, nu = O.adamw_step(p, g, np.zeros(3, np.float32), np.zeros(3, np.float32), 1, 0.1, wd=0.0)
+    np.testing.assert_allclose(p1, p - 0.1 * np.sign(g), atol=5e-3)          # step 1: mu_hat / sqrt(nu_hat) = sign(g) up to bf16(mu)
+    assert np.all(O._bf16(mu) == mu)
+    p2, _, _ = O.adamw_step(p, g, np.zeros(3, np.float32), np.zeros(3, np.float32), 1, 0.1, wd=0.5)
+    np.testing.assert_allclose(p2 - p1, -0.1 * 0.5 * p, atol=1e-6)           # decoupled decay, scaled by lr
+    _, mu_c, _ = O.adamw_step(p, g * 100, np.zeros(3, np.float32), np.zeros(3, np.float32), 1, 0.1, clip_norm=1.0)
+    assert abs(np.linalg.norm(mu_c) / 0.1 - 1.0) < 1e-2                      # clipped to norm 1 before the moments
+    cfg = preset("vit-tiny-patch16-160")
+    m = create_model(cfg, state_dict=synth.make_state_dict(cfg))
+    dec = {n for n, q in m.named_parameters() if training.default_decay_filter(n, q)}
+    assert "visual.conv1.weight" in dec and "text_projection" in dec and "transformer.resblocks.0.mlp.c_fc.weight" in dec
+    assert not ({"logit_scale", "token_embedding.weight", "positional_embedding", "visual.positional_embedding",
+                 "visual.class_embedding", "ln_final.weight", "transformer.resblocks.0.mlp.c_fc.bias"} & dec)
