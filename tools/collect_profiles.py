@@ -37,7 +37,8 @@ Mv_main = (batch - 1) * Lv            # the tower peels the last image onto a si
 PEAK_TF, PEAK_GBS = 2500.0, 8000.0
 # kernels whose per-launch algorithmic work is unambiguous on this workload (vision tower main part)
 known = {
-    "gemm_bf16_persist<1, true>": ("mfma", 2.0 * Mv_main * Fv * Dv, "vision mlp.c_fc (LN fold + erf-GELU)"),
+    "gemm_bf16_persist<1, true, true>": ("mfma", 2.0 * Mv_main * Fv * Dv, "vision mlp.c_fc (LN fold + erf-GELU, direct-store epilogue)"),
+    "gemm_bf16_persist<1, true>": ("mfma", 2.0 * Mv_main * Fv * Dv, "vision mlp.c_fc (LN fold + erf-GELU) [round-1 kernel name]"),
     "rowstats_rows<2>": ("hbm", None, "row mean/rstd of the residual stream (both towers, tail images: mixed sizes)"),
 }
 table = []
@@ -69,7 +70,7 @@ def pmc(sub, counter):
     if not f:
         return None
     vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
-            if r["Counter_Name"] == counter and "gemm_bf16_persist<1, true>" in r["Kernel_Name"]]
+            if r["Counter_Name"] == counter and "gemm_bf16_persist<1, true" in r["Kernel_Name"]]
     return vals
 
 
@@ -77,9 +78,9 @@ fe, wr = pmc("pmc_fetch", "FETCH_SIZE"), pmc("pmc_write", "WRITE_SIZE")
 if fe and wr:
     fkb, wkb = statistics.median(fe), statistics.median(wr)
     json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernel-trace only) on `python3 bench.py --steps 2 "
-                       "--warmup 1 --cpu-seconds 0`; per-launch medians over the launches of gemm_bf16_persist<1, true>; bytes = "
+                       "--warmup 1 --cpu-seconds 0`; per-launch medians over the launches of gemm_bf16_persist<1, true, *>; bytes = "
                        "(2*FETCH_SIZE + WRITE_SIZE) KiB: gfx950 FETCH_SIZE counts half of wide coalesced reads (MI355X_MICROARCH.md)",
-               "model": model, "batch": batch, "kernel": "gemm_bf16_persist<1, true>", "launches": len(fe),
+               "model": model, "batch": batch, "kernel": "gemm_bf16_persist<1, true, *> (vision mlp.c_fc)", "launches": len(fe),
                "FETCH_SIZE_KB_median": fkb, "WRITE_SIZE_KB_median": wkb,
                "gemm_fc_bytes_per_launch": (2 * fkb + wkb) * 1024.0,
                "algorithmic_bytes_per_launch": 2.0 * (Mv_main * Dv + Fv * Dv + Mv_main * Fv)},
