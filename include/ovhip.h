@@ -343,7 +343,8 @@ int       ov_tower_set_block_fp8(ov_tower* t, int layer, const ov_block_fp8* q);
  * [layer] = MLP hidden, [layers + layer] = attention output, [2 * layers ...) = the same two sets as recorded during the
  * running forward (rolled into the first half at the top of the next one).  mode 0: off (both are written in bf16 and re-quantised row by row); 1: same, and
  * their running maxima are recorded into amax (calibration); 2: the producers (c_fc epilogue, attention epilogue for head_dim 64)
- * write e4m3 directly with the scale 2 * amax / 448 and the consumers (c_proj, out_proj) read it with that scalar scale. */
+ * write e4m3 directly with the scale 2 * amax / 448 and the consumers (c_proj, out_proj) read it with that scalar scale; 3: as 2
+ * but FROZEN: the recorded maxima are never rolled into the scales (bitwise repeatable, batch-composition invariant results). */
 int       ov_tower_set_fp8_hidden_scale(ov_tower* t, float* amax, int mode);
 size_t    ov_tower_workspace_bytes(const ov_tower* t, int B, int L);
 /* x[B*L, D] bf16 is updated in place through all `layers` blocks. */

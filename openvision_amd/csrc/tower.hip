@@ -243,7 +243,7 @@ extern "C" int ov_tower_set_block_fp8(ov_tower* t, int layer, const ov_block_fp8
 }
 
 extern "C" int ov_tower_set_fp8_hidden_scale(ov_tower* t, float* h_amax, int mode) {
-    if (!t || mode < 0 || mode > 2 || (mode > 0 && !h_amax)) return OV_ERR_INVALID;
+    if (!t || mode < 0 || mode > 3 || (mode > 0 && !h_amax)) return OV_ERR_INVALID;
     t->h_amax = h_amax;
     t->h_mode = mode;
     return OV_OK;
@@ -352,7 +352,7 @@ int run_block_fp8(const ov_tower_cfg& c, const ov_block_weights& w, const ov_blo
     } while (0)
     OV_STEP(OV_PROF_LN, ov_layernorm_quant_fp8(x, D, w.ln1_w, w.ln1_b, q8, D, qs, M, D, c.ln_eps, stream));
     OV_STEP(OV_PROF_GEMM_QKV, ov_gemm_fp8(q8, D, q.qkv_w8, D, qs, q.qkv_s, q.qkv_b, big, ldb, M, 3 * D, D, OV_EPI_BIAS, nullptr, 0, stream));
-    if (h_mode == 2 && hd == 64) {
+    if (h_mode >= 2 && hd == 64) {
         // static scale: the attention epilogue writes e4m3 itself (into the fp8 activation buffer, free at this point)
         OV_STEP(OV_PROF_ATTN, ov_attention_fp8out(big, ldb, q8, D, B, L, H, hd, scale, a_amax, a_next, stream));
         OV_STEP(OV_PROF_GEMM_OUT, ov_gemm_fp8_static(q8, D, q.out_w8, D, nullptr, a_amax, q.out_s, w.out_b, x, D, nullptr, nullptr, M, D, D,
@@ -363,7 +363,7 @@ int run_block_fp8(const ov_tower_cfg& c, const ov_block_weights& w, const ov_blo
         OV_STEP(OV_PROF_GEMM_OUT, ov_gemm_fp8(q8, D, q.out_w8, D, qs, q.out_s, w.out_b, x, D, M, D, D, OV_EPI_BIAS_RESIDUAL, x, D, stream));
     }
     OV_STEP(OV_PROF_LN, ov_layernorm_quant_fp8(x, D, w.ln2_w, w.ln2_b, q8, D, qs, M, D, c.ln_eps, stream));
-    if (h_mode == 2) {
+    if (h_mode >= 2) {
         // static hidden scale: c_fc quantises its own output (e4m3 bytes, pitch F, in the `big` region), c_proj reads it as is
         unsigned char* h8 = (unsigned char*)big;
         OV_STEP(fc_cls, ov_gemm_fp8_static(q8, D, q.fc_w8, D, qs, nullptr, q.fc_s, q.fc_b, h8, F, h_amax, h_next, M, F, D, gelu, nullptr, 0, stream));

@@ -404,12 +404,12 @@ class _TowerHandle:
             self.h_amax = torch.zeros(4 * len(blocks), dtype=torch.float32, device=b0.attn.in_proj_weight.device)
             check(lib.ov_tower_set_fp8_hidden_scale(self.handle, ptr(self.h_amax), 1), "ov_tower_set_fp8_hidden_scale")
 
-    def freeze_fp8_scales(self) -> None:
+    def freeze_fp8_scales(self, delayed: bool = True) -> None:
         if not self.fp8:
             raise _lib.OvhipError("freeze_fp8_scales: the tower is not in fp8 precision")
         if not bool((self.h_amax[: 2 * self.layers] > 0).all()):
             raise _lib.OvhipError("freeze_fp8_scales: run at least one forward in fp8 precision first (calibration)")
-        check(_lib.load().ov_tower_set_fp8_hidden_scale(self.handle, ptr(self.h_amax), 2), "ov_tower_set_fp8_hidden_scale")
+        check(_lib.load().ov_tower_set_fp8_hidden_scale(self.handle, ptr(self.h_amax), 2 if delayed else 3), "ov_tower_set_fp8_hidden_scale")
 
     def __del__(self):
         try:
@@ -488,10 +488,13 @@ class Transformer(nn.Module):
             raise ValueError("precision must be 'bf16' or 'fp8'")
         self._cache.precision = precision
 
-    def freeze_fp8_scales(self) -> None:
+    def freeze_fp8_scales(self, delayed: bool = True) -> None:
         """fp8 precision: after at least one forward (which records the per-layer maximum of the MLP hidden), switch c_fc -> c_proj to
-        the fused hand-over with a static scale (2 x the recorded maximum / 448) -- no bf16 round trip of the hidden."""
-        self.tower().freeze_fp8_scales()
+        the fused hand-over with a static scale (2 x the recorded maximum / 448) -- no bf16 round trip of the hidden.  delayed=True
+        (training-style): every forward first rolls the maxima recorded by the previous one into the scales (they only grow, and a
+        changed scale re-rounds every e4m3 value downstream: results are then NOT bitwise repeatable from call to call);
+        delayed=False (serving): the scales stay as they are: repeatable and independent of the batch composition."""
+        self.tower().freeze_fp8_scales(delayed)
 
     def forward(self, x: torch.Tensor, attn_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
         if attn_mask is not None:
@@ -682,10 +685,10 @@ class CLIP(nn.Module):
         self.visual.transformer.set_precision(precision)
         self.transformer.set_precision(precision)
 
-    def freeze_fp8_scales(self) -> None:
+    def freeze_fp8_scales(self, delayed: bool = True) -> None:
         """fp8 precision, after a calibration forward of both towers: static scales for the MLP hidden (see Transformer)."""
-        self.visual.transformer.freeze_fp8_scales()
-        self.transformer.freeze_fp8_scales()
+        self.visual.transformer.freeze_fp8_scales(delayed)
+        self.transformer.freeze_fp8_scales(delayed)
 
     def use_graphs(self, max_batch: int = 8) -> None:
         """Replay encode_image / encode_text calls of at most `max_batch` rows as captured hipGraphs (0 turns it off).  For the

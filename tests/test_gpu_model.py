@@ -463,7 +463,12 @@ def test_fp8_config5_per_gpu_shape_b256_microbatches():
         step()                                                   # delayed scaling settles
         i8, t8, s8 = step()
         l8 = float(ClipLoss()(i8, t8, s8))
+        # delayed scales keep creeping (a changed scale re-rounds everything downstream, which moves later maxima): row results are
+        # repeatable and batch-invariant only once the scales are FROZEN (serving mode)
+        m.freeze_fp8_scales(delayed=False)
+        full = m.encode_image(imgs[0], normalize=True)
         part = m.encode_image(imgs[0][:100], normalize=True)
+        full_again = m.encode_image(imgs[0], normalize=True)
     finally:
         m.set_precision("bf16")
     stats = {}
@@ -483,7 +488,8 @@ def test_fp8_config5_per_gpu_shape_b256_microbatches():
     # nearest-neighbour structure survives: each fp8 image embedding is closest to its own bf16 embedding
     nn = (i8 @ i16.T).argmax(dim=1).cpu()
     assert torch.equal(nn, torch.arange(mb * b))
-    assert (1 - torch.nn.functional.cosine_similarity(part, i8[:100])).max().item() < 1e-6     # static scales: rows independent
+    assert torch.equal(part, full[:100]) and torch.equal(full, full_again)        # frozen scales: rows independent, bitwise repeatable
+    assert (1 - torch.nn.functional.cosine_similarity(full, i16[:b])).max().item() < 0.12
 
 
 def test_checkpoint_dir_to_device(tiny, tmp_path):
