@@ -92,6 +92,9 @@ def pre_tokenize(text: str) -> List[str]:
     return words
 
 
+INNER_CONTEXT_LENGTH = 80      # CustomTokenizer(vocab_file, context_length=80, ...) inside CLIPS_Tokenizer (tokenizer.py:564)
+
+
 class WordPieceTokenizer:
     """Drop-in for the reference's ``CLIPS_Tokenizer``: ``tok(texts) -> LongTensor [N, context_length]``."""
 
@@ -141,8 +144,9 @@ class WordPieceTokenizer:
 
     def frame(self, ids: Sequence[int], context_length: int) -> List[int]:
         """CustomTokenizer.tokenize + pad_and_add_class_token (tokenizer.py:534-550); the reference truncates to its own
-        context_length (80) - 3 pieces and pads to ``max_length - 1``."""
-        out = [self.bos_token] + list(ids[: self.context_length - 3]) + [self.eos_token]
+        context_length (80: hard-wired where CLIPS_Tokenizer builds it, tokenizer.py:564) - 3 pieces whatever the OUTER context
+        length is, and pads to ``max_length - 1``."""
+        out = [self.bos_token] + list(ids[: INNER_CONTEXT_LENGTH - 3]) + [self.eos_token]
         if len(out) < context_length - 1:
             out += [self.pad_token] * (context_length - 1 - len(out))
         return out + [self.class_token]

@@ -32,3 +32,16 @@ def test_framing_and_edge_cases():
     assert normalize("Café\tOΔΟΣ") == "cafe oδοσ"                     # accents stripped, per-character lower case
     assert pre_tokenize("it's (ok)") == ["it", "'", "s", "(", "ok", ")"]
     assert tok("x", context_length=16).shape == (1, 16)
+
+
+def test_truncation_follows_the_inner_tokenizer_not_the_outer_context_length():
+    """CLIPS_Tokenizer hard-wires its inner CustomTokenizer to context_length 80 (tokenizer.py:564): captions are cut to 77 pieces
+    whatever the outer context_length; a shorter outer length then yields a ragged row, which raises (torch.tensor on ragged lists)."""
+    import pytest
+    from openvision_amd.tokenizer import WordPieceTokenizer
+    tk = WordPieceTokenizer(context_length=128)
+    row = tk(["word " * 200])[0]
+    assert row.shape[0] == 128 and int((row != 0).sum()) == 77 + 3          # bos + 77 pieces + eos + class token, padded to 128
+    assert int(row[-1]) == 101 and int(row[78]) == 2
+    with pytest.raises(ValueError):
+        WordPieceTokenizer(context_length=64)(["word " * 200])
