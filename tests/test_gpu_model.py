@@ -265,30 +265,34 @@ def test_full_size_batch256_properties():
     assert abs(float(ClipLoss()(ni[perm].contiguous(), nt[perm].contiguous(), s)) - full) < 2e-5   # pair order is irrelevant
 
 
-def test_base16_224_against_oracle():
+@pytest.mark.parametrize("variant", ["v1", "sharp"])
+def test_base16_224_against_oracle(variant):
     """A size the golden files do not hold (B/16@224: 197 tokens, 12 heads, E=512, text width 512): checked against the
-    oracle run here on the CPU in fp32."""
+    oracle run here on the CPU in fp32, on the benign and on the discriminating weight set."""
     from oracle import clip_ref as R
     cfg = preset("vit-base-patch16-224")
-    sd = synth.make_state_dict(cfg)
+    sd = synth.make_state_dict(cfg, 0, variant)
     m = create_model(cfg, device=DEV, state_dict=sd)
-    img, tok = synth.make_images(3, 224, seed=2), synth.make_captions(3, seed=2)
+    img = synth.make_images(3, 224, seed=2) if variant == "v1" else synth.make_structured_images(3, 224, seed=2)
+    tok = synth.make_captions(3, seed=2)
     ni, nt, s = m(img.to(DEV), tok.to(DEV))
     ri, rt, rs = R.clip_forward(img, tok, sd, cfg)
     assert one_minus_cos(ni, ri) < COS_TOL and one_minus_cos(nt, rt) < COS_TOL
     assert abs(float(ClipLoss()(ni, nt, s)) - float(R.clip_loss(ri, rt, rs))) < 0.05
 
 
+@pytest.mark.parametrize("variant", ["v1", "sharp"])
 @pytest.mark.parametrize("width,head_width", [(320, 80), (576, 72)])
-def test_head_dims_of_h14_and_so400m(width, head_width):
+def test_head_dims_of_h14_and_so400m(width, head_width, variant):
     """head_dim 80 (OpenVision H/14) and 72 (So400m, with its 3.7362 MLP ratio -> padded hidden width) against the oracle."""
     from oracle import clip_ref as R
     cfg = preset("vit-tiny-patch16-160")
     cfg["vision_cfg"] = dict(cfg["vision_cfg"], width=width, head_width=head_width, layers=2, mlp_ratio=3.7362)
     cfg["text_cfg"] = dict(cfg["text_cfg"], width=width, heads=width // head_width, layers=2, mlp_ratio=3.7362)
-    sd = synth.make_state_dict(cfg)
+    sd = synth.make_state_dict(cfg, 0, variant)
     m = create_model(cfg, device=DEV, state_dict=sd)
-    img, tok = synth.make_images(3, 160, seed=4), synth.make_captions(3, seed=4)
+    img = synth.make_images(3, 160, seed=4) if variant == "v1" else synth.make_structured_images(3, 160, seed=4)
+    tok = synth.make_captions(3, seed=4)
     ni, nt, s = m(img.to(DEV), tok.to(DEV))
     ri, rt, rs = R.clip_forward(img, tok, sd, cfg)
     assert one_minus_cos(ni, ri) < COS_TOL and one_minus_cos(nt, rt) < COS_TOL
