@@ -368,7 +368,12 @@ constexpr int SMEM_PERSIST = IMG_OFF + 8 * 2048;     // 152 KiB of the CU's 160 
 //     fq 0: n  0- 7 | fq 2: n  8-15 | fq 1: n 16-23 | fq 3: n 24-31      (+ 32 for the pair j0 = 2)
 // so one global_store_dwordx4 writes 64 contiguous bytes of each of the wave's 16 rows -- no transposition through LDS (the 8-pass
 // LDS image of the previous version cost 4 ds_write_b64 + 2 ds_read_b128 and an LDS round trip per pass).
-template <int EPI, bool FOLD>
+// MAPPED = the row maps out_group / resid_mod are in use (the patch embedding's GEMM only; a kernel template parameter chosen by the
+// launcher).  Without them the output / residual row IS the tile row: no unsigned division by the map parameters (hipcc if-converts
+// `g.out_group ? m + m / g.out_group + 1 : m` and computes the software division on every store), and row pointers are one
+// 64-bit multiply per lane, stepped by whole rows, instead of one per store -- ~250 of the ~500 (bias) to ~1200 (residual) VALU
+// instructions of the epilogue were such address arithmetic.
+template <int EPI, bool FOLD, bool MAPPED>
 __device__ __forceinline__ void epilogue_stream(const GemmArgs& g, f32x4_t (&acc)[8][4], const char* prm,
                                                 int64_t m0, int n0, int wave, int lane, bool edge, unsigned long long* wst) {
     const int wm = wave >> 2, wn = wave & 3;
@@ -381,7 +386,18 @@ __device__ __forceinline__ void epilogue_stream(const GemmArgs& g, f32x4_t (&acc
     // 4-7 once four accumulator rows have been retired (register room), and only then the first store.
     u32x4_t rv[8][2];
     const int nc0 = ncol0 ? n_lo : g.N - 8, nc1 = ncol1 ? n_lo + 32 : g.N - 8;
+    // !MAPPED: this lane's row of pass 0 (clamped for the residual read: rows past M re-read row M - 1, never stored)
+    const int64_t mbase = m0 + wm * 128 + fr;
+    ov_bf16* const cbase = !MAPPED ? g.C + mbase * g.ldc + n_lo : nullptr;
     auto load_resid = [&](int i) {      // inline asm: the waits below are counted by hand (hipcc would use vmcnt(0))
+        if (!MAPPED) {
+            int64_t m = mbase + i * 16;
+            m = m < g.M ? m : g.M - 1;
+            const ov_bf16* src = g.R + m * g.ldr;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rv[i][0]) : "v"(src + nc0));
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rv[i][1]) : "v"(src + nc1));
+            return;
+        }
         unsigned m = (unsigned)m0 + wm * 128 + i * 16 + fr;
         m = m < (unsigned)g.M ? m : (unsigned)g.M - 1;
         const unsigned rrow = g.resid_mod ? (m % (unsigned)g.resid_mod) + g.resid_off : m;
@@ -423,8 +439,13 @@ __device__ __forceinline__ void epilogue_stream(const GemmArgs& g, f32x4_t (&acc
     u32x4_t vo[8][2];
     auto put = [&](int i) {
         const unsigned m = (unsigned)m0 + wm * 128 + i * 16 + fr;
-        const unsigned orow = g.out_group ? m + m / (unsigned)g.out_group + 1 : m;
-        ov_bf16* dst = g.C + (int64_t)orow * g.ldc + n_lo;
+        ov_bf16* dst;
+        if (!MAPPED) {
+            dst = cbase + (int64_t)(i * 16) * g.ldc;
+        } else {
+            const unsigned orow = g.out_group ? m + m / (unsigned)g.out_group + 1 : m;
+            dst = g.C + (int64_t)orow * g.ldc + n_lo;
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             u32x4_t o = vo[i][h];
@@ -499,7 +520,7 @@ __device__ __forceinline__ void epilogue_stream(const GemmArgs& g, f32x4_t (&acc
 
 // The same epilogue with the 16-byte stores made row-contiguous through a wave-local LDS image (8 lanes x 16 B = one 128-B line):
 // coalesced stores (16 TA cycles per instruction against ~70 for the row-per-lane form above), at the price of the LDS round trip.
-template <int EPI, bool FOLD>
+template <int EPI, bool FOLD, bool MAPPED>
 __device__ __forceinline__ void epilogue_stream_lds(const GemmArgs& g, f32x4_t (&acc)[8][4], char* img, const char* prm,
                                                 int64_t m0, int n0, int wave, int lane, bool edge, unsigned long long* wst) {
     const int wm = wave >> 2, wn = wave & 3;
@@ -556,6 +577,7 @@ __device__ __forceinline__ void epilogue_stream_lds(const GemmArgs& g, f32x4_t (
     char* const wr = img + fr * 128 + (fq & 1) * 8;
     const int wsw = fr & 7;
     const char* const rd = img + er * 128 + ((ec ^ er) << 4);       // rows er and er + 8 share (row & 7)
+    ov_bf16* const cbase_lds = !MAPPED ? g.C + (m0 + wm * 128 + er) * g.ldc + n : nullptr;
     u32x4_t vo[8][2];
     auto put = [&](int i) {
 #pragma unroll
@@ -568,6 +590,10 @@ __device__ __forceinline__ void epilogue_stream_lds(const GemmArgs& g, f32x4_t (
                                        bf16hi_to_f32(o[e]) + bf16hi_to_f32(rv[i][it][e]));
             }
             const unsigned m = (unsigned)m0 + wm * 128 + i * 16 + it * 8 + er;
+            if (!MAPPED) {   // no row map: the lane's row pointer of pass 0, stepped by whole rows
+                if (m < (unsigned)g.M && ncol) *(u32x4_t*)(cbase_lds + (int64_t)(i * 16 + it * 8) * g.ldc) = o;
+                continue;
+            }
             if (m < (unsigned)g.M && ncol) {
                 const unsigned orow = g.out_group ? m + m / (unsigned)g.out_group + 1 : m;
                 *(u32x4_t*)(g.C + (int64_t)orow * g.ldc + n) = o;
@@ -637,7 +663,7 @@ __device__ __forceinline__ void epilogue_stream_lds(const GemmArgs& g, f32x4_t (
 template <int V> struct IntC { static constexpr int value = V; };
 struct TileSrc { const ov_bf16* a0; const ov_bf16* a1; const ov_bf16* w0; const ov_bf16* w1; };   // per-lane staging sources
 
-template <int EPI, bool FOLD, bool DIRECT>
+template <int EPI, bool FOLD, bool DIRECT, bool MAPPED>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist(const GemmArgs g) {
     __shared__ __attribute__((aligned(16))) char smem[DIRECT ? IMG_OFF : SMEM_PERSIST];
     const int tid = threadIdx.x;
@@ -881,8 +907,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist(const GemmArgs 
         const bool edge = (m0 + BM > g.M) || (n0 + BN > g.N);      // an edge tile issues fewer than 16 stores per wave
         if (wst != nullptr && lane == 0) wst[1] = __builtin_amdgcn_s_memtime();
         if (g.epi_prio && wm == 1) __builtin_amdgcn_s_setprio(1);
-        if (DIRECT) epilogue_stream<EPI, FOLD>(g, acc, smem + PRM_OFF + pslot * 4096, m0, n0, wave, lane, edge, wst);
-        else epilogue_stream_lds<EPI, FOLD>(g, acc, smem + IMG_OFF + wave * 2048, smem + PRM_OFF + pslot * 4096, m0, n0, wave, lane, edge, wst);
+        if (DIRECT) epilogue_stream<EPI, FOLD, MAPPED>(g, acc, smem + PRM_OFF + pslot * 4096, m0, n0, wave, lane, edge, wst);
+        else epilogue_stream_lds<EPI, FOLD, MAPPED>(g, acc, smem + IMG_OFF + wave * 2048, smem + PRM_OFF + pslot * 4096, m0, n0, wave, lane, edge, wst);
         if (g.epi_prio && wm == 1) __builtin_amdgcn_s_setprio(0);
         stamp(3);
         ++titer;
@@ -968,6 +994,8 @@ int launch(GemmArgs a, hipStream_t st) {
     if (min_persist_env == -2) { const char* e = getenv("OVHIP_GEMM_MINPERSIST"); min_persist_env = e ? atoi(e) : -1; }
     const int min_persist = min_persist_env >= 0 ? min_persist_env : num_cus();
     if (var == 0 && (nwg < min_persist || a.K < 3 * BK)) var = 2;
+    // row maps (the patch embedding's GEMM) exist in the persistent kernel for the bias and residual epilogues only
+    if (var == 0 && (a.out_group != 0 || a.resid_mod != 0) && EPI != OV_EPI_BIAS && EPI != OV_EPI_BIAS_RESIDUAL) var = 2;
     if (var == 1) {
         hipLaunchKernelGGL(gemm_bf16_256x256<EPI>, dim3(nwg), dim3(NTHREADS), 0, st, a);
     } else if (var == 2) {
@@ -980,20 +1008,25 @@ int launch(GemmArgs a, hipStream_t st) {
         // epilogue (QKV, projections): LDS-transposed coalesced stores measure faster in the model (9.5-9.8 against 10.0-10.3 ms per
         // step for the QKV GEMMs); OVHIP_GEMM_EPI_DIRECT=1 selects the direct form there too.
         constexpr bool CAN_FOLD = EPI != OV_EPI_BIAS_RESIDUAL;
+        const bool mapped = a.out_group != 0 || a.resid_mod != 0;          // row maps: the patch embedding's GEMM only
         if (EPI == OV_EPI_BIAS) {
             static int direct0 = -1;
             if (direct0 < 0) { const char* e = getenv("OVHIP_GEMM_EPI_DIRECT"); direct0 = (e && e[0] == '1') ? 1 : 0; }
-            if (a.colsum != nullptr) {
-                if (direct0) hipLaunchKernelGGL((gemm_bf16_persist<OV_EPI_BIAS, true, true>), grid, blk, 0, st, a);
-                else hipLaunchKernelGGL((gemm_bf16_persist<OV_EPI_BIAS, true, false>), grid, blk, 0, st, a);
+            if (a.colsum != nullptr) {          // LN fold: never with row maps
+                if (direct0) hipLaunchKernelGGL((gemm_bf16_persist<OV_EPI_BIAS, true, true, false>), grid, blk, 0, st, a);
+                else hipLaunchKernelGGL((gemm_bf16_persist<OV_EPI_BIAS, true, false, false>), grid, blk, 0, st, a);
+            } else if (mapped) {
+                hipLaunchKernelGGL((gemm_bf16_persist<OV_EPI_BIAS, false, false, true>), grid, blk, 0, st, a);
             } else {
-                if (direct0) hipLaunchKernelGGL((gemm_bf16_persist<OV_EPI_BIAS, false, true>), grid, blk, 0, st, a);
-                else hipLaunchKernelGGL((gemm_bf16_persist<OV_EPI_BIAS, false, false>), grid, blk, 0, st, a);
+                if (direct0) hipLaunchKernelGGL((gemm_bf16_persist<OV_EPI_BIAS, false, true, false>), grid, blk, 0, st, a);
+                else hipLaunchKernelGGL((gemm_bf16_persist<OV_EPI_BIAS, false, false, false>), grid, blk, 0, st, a);
             }
         } else if (CAN_FOLD && a.colsum != nullptr) {
-            hipLaunchKernelGGL((gemm_bf16_persist<EPI, CAN_FOLD, true>), grid, blk, 0, st, a);
+            hipLaunchKernelGGL((gemm_bf16_persist<EPI, CAN_FOLD, true, false>), grid, blk, 0, st, a);
+        } else if (EPI == OV_EPI_BIAS_RESIDUAL && mapped) {
+            hipLaunchKernelGGL((gemm_bf16_persist<OV_EPI_BIAS_RESIDUAL, false, true, true>), grid, blk, 0, st, a);
         } else {
-            hipLaunchKernelGGL((gemm_bf16_persist<EPI, false, true>), grid, blk, 0, st, a);
+            hipLaunchKernelGGL((gemm_bf16_persist<EPI, false, true, false>), grid, blk, 0, st, a);
         }
     }
     OV_LAUNCH_CHECK();
