@@ -11,8 +11,10 @@
 //     per-lane SOURCE address and again on the ds_read_b128 side;
 //   * each wave owns a 128(m) x 64(n) sub-tile = 8 x 4 v_mfma_f32_16x16x32_bf16 accumulators;
 //     W is fed as the MFMA A operand so a lane ends up holding 4 consecutive n for one m;
-//   * epilogue: bias / GELU in fp32 on the accumulators, bf16 pack, transpose through (swizzled) LDS,
-//     then 16-byte row-contiguous stores with the residual added on the way out;
+//   * epilogue: bias / LN fold / GELU in fp32 on the accumulators, bf16 pack, then either a transposition through a (swizzled)
+//     wave-local LDS image and row-contiguous 16-byte stores (bias epilogue of the persistent kernel, every epilogue of the
+//     non-persistent kernels) or a v_permlane16_swap exchange and row-per-lane 16-byte stores (GELU and residual epilogues of the
+//     persistent kernel); the residual is added on the way out.  All forms perform the same arithmetic in the same order;
 //   * workgroup id -> tile map is XCD-aware: each XCD's L2 sees a contiguous run of tiles that walk n
 //     fastest, so the 32 tiles resident on an XCD share A row-panels and the whole of W.
 #include "common.h"
