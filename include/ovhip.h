@@ -93,6 +93,13 @@ int ov_gemm(const ov_bf16* A, int64_t lda, const ov_bf16* W, int64_t ldw, const 
 int ov_gemm_batched(const ov_bf16* A, int64_t lda, int64_t stride_a, const ov_bf16* W, int64_t ldw, int64_t stride_w, ov_bf16* C,
                     int64_t ldc, int64_t stride_c, int64_t M, int N, int K, int batch, ov_stream_t stream);
 
+/* Split-K partials of C = P^T Q with BOTH operands row-major over the contraction rows (P [Mc, NI], Q [Mc, NJ]): partial z contracts
+ * rows [z * chunk, min(Mc, (z + 1) * chunk)) into C + z * stride_c (bf16 [NI, NJ], no bias).  The weight-gradient product
+ * dW = dY^T X of ov_linear_backward without explicit transposes (transposing LDS reads, ds_read_b64_tr_b16).  Mc % 64 == 0,
+ * chunk % 64 == 0, (batch - 1) * chunk < Mc <= batch * chunk, NI / NJ / leading dimensions % 8 == 0. */
+int ov_gemm_tn_batched(const ov_bf16* P, int64_t ldp, const ov_bf16* Q, int64_t ldq, ov_bf16* C, int64_t ldc, int64_t stride_c, int64_t Mc,
+                       int NI, int NJ, int64_t chunk, int batch, ov_stream_t stream);
+
 /* LayerNorm folded into the following Linear (LN(x) W^T + b without materialising LN(x)):
  *   C = epilogue( rstd[m] * (x W'^T - mean[m] * colsum[n]) + cvec[n] ),
  *   W'[n,k] = bf16(gamma[k] W[n,k]), colsum[n] = sum_k W'[n,k], cvec[n] = sum_k beta[k] W[n,k] + b[n]   (built once at pack time),

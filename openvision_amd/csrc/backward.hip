@@ -23,6 +23,8 @@ extern "C" int ov_attention_backward(const ov_bf16* qkv, int64_t ld_qkv, const o
 extern "C" size_t ov_attention_backward_workspace_bytes(int B, int L, int H, int hd);
 extern "C" int ov_gemm_batched(const ov_bf16* A, int64_t lda, int64_t stride_a, const ov_bf16* W, int64_t ldw, int64_t stride_w,
                                ov_bf16* C, int64_t ldc, int64_t stride_c, int64_t M, int N, int K, int batch, ov_stream_t stream);
+extern "C" int ov_gemm_tn_batched(const ov_bf16* P, int64_t ldp, const ov_bf16* Q, int64_t ldq, ov_bf16* C, int64_t ldc, int64_t stride_c,
+                                  int64_t Mc, int NI, int NJ, int64_t chunk, int batch, ov_stream_t stream);
 
 namespace {
 
@@ -306,14 +308,23 @@ inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 // `chunk` rows (a multiple of 64) to put ~2 workgroups on every CU; rows past M are zeros written by the transposes
 struct SplitK { int nz; int64_t chunk, mp; };
 inline SplitK plan_splitk(int64_t M, int N, int K) {
+    // The dW kernels run one 256 x 256 tile per workgroup and one workgroup per CU at a time: the launch takes
+    // ceil(tiles * nz / CUs) rounds of (rows per range) / 64 K-tiles.  Pick the nz in [1, 32] with the shortest launch (ties: fewer
+    // partials, i.e. less fp32 summing): e.g. QKV (48 tiles): nz = 16 -> 768 workgroups = 3 full rounds of 256 CUs, where the former
+    // "about 512 workgroups" rule gave 11 ranges = 528 workgroups = two full rounds and a third one for 16 of them.
     const int64_t tiles = (int64_t)((N + 255) / 256) * ((K + 255) / 256);
-    int64_t nz = (512 + tiles - 1) / tiles;
-    if (nz > 32) nz = 32;
+    const int ncu = ov_num_cus();
     const int64_t max_nz = (M + 511) / 512;                       // at least 8 K-tiles per range
-    if (nz > max_nz) nz = max_nz;
-    if (nz < 1) nz = 1;
+    int64_t best_nz = 1, best_cost = -1;
+    for (int64_t nz = 1; nz <= 32 && nz <= (max_nz < 1 ? 1 : max_nz); ++nz) {
+        const int64_t chunk = pad64((M + nz - 1) / nz);
+        const int64_t real_nz = (M + chunk - 1) / chunk;
+        const int64_t rounds = (tiles * real_nz + ncu - 1) / ncu;
+        const int64_t cost = rounds * (chunk / 64 + 6) * 16 + real_nz;      // + 6: tile prologue / epilogue in K-tile units
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_nz = real_nz; }
+    }
     SplitK p;
-    p.chunk = pad64((M + nz - 1) / nz);
+    p.chunk = pad64((M + best_nz - 1) / best_nz);
     p.nz = (int)((M + p.chunk - 1) / p.chunk);
     p.mp = p.chunk * p.nz;
     return p;
@@ -375,7 +386,25 @@ extern "C" int ov_linear_backward(const ov_bf16* dY, int64_t lddy, const ov_bf16
         if ((rc = launch_transpose(W, ldw, N, N, K, Wt, N, st)) != OV_OK) return rc;
         if ((rc = ov_gemm(dY, lddy, Wt, N, nullptr, dX, lddx, M, K, N, OV_EPI_BIAS, nullptr, 0, 0, 0, 0, stream)) != OV_OK) return rc;
     }
-    if (dW) {       // dW[N, K] = dY^T[N, M] . X[M, K]  =  ov_gemm(A = dY^T [N, Mpad], "W" = X^T [K, Mpad]) contracting over Mpad (zeros past M)
+    // dW = dY^T X straight from the row-major operands (transposing LDS reads) when the row count is a multiple of the 64-row
+    // K-tile (B * L of every tower is: 257 * 256, 80 * 256, ...); OVHIP_DW_TRANSPOSE=1 forces the explicit-transpose route.  Both
+    // routes accumulate the same products in the same order: bitwise the same dW.
+    static int force_tr = -1;
+    if (force_tr < 0) { const char* e = getenv("OVHIP_DW_TRANSPOSE"); force_tr = (e && e[0] == '1') ? 1 : 0; }
+    const bool tn = dW && (M % 64 == 0) && !force_tr;
+    if (dW && tn) {
+        if (sp.nz == 1) {
+            if ((rc = ov_gemm_tn_batched(dY, lddy, X, ldx, dW, lddw, 0, M, N, K, sp.chunk, 1, stream)) != OV_OK) return rc;
+        } else {
+            if ((rc = ov_gemm_tn_batched(dY, lddy, X, ldx, dWp, K, (int64_t)N * K, M, N, K, sp.chunk, sp.nz, stream)) != OV_OK) return rc;
+            const int64_t total8 = (int64_t)N * K / 8;
+            int64_t blocks = (total8 + 255) / 256;
+            if (blocks > 4096) blocks = 4096;
+            hipLaunchKernelGGL(splitk_sum, dim3((unsigned)blocks), dim3(256), 0, st, (const ov_bf16*)dWp, (int64_t)N * K, sp.nz, total8, K / 8,
+                               dW, lddw);
+            OV_LAUNCH_CHECK();
+        }
+    } else if (dW) {       // dW[N, K] = dY^T[N, M] . X[M, K]  =  ov_gemm(A = dY^T [N, Mpad], "W" = X^T [K, Mpad]) contracting over Mpad (zeros past M)
         if (sp.chunk > 0x7fffffffLL) return OV_ERR_UNSUPPORTED;
         if ((rc = launch_transpose(dY, lddy, M, mp, N, dYt, mp, st, db ? part : nullptr)) != OV_OK) return rc;   // + per-tile column sums
         if ((rc = launch_transpose(X, ldx, M, mp, K, Xt, mp, st)) != OV_OK) return rc;
@@ -392,7 +421,7 @@ extern "C" int ov_linear_backward(const ov_bf16* dY, int64_t lddy, const ov_bf16
             OV_LAUNCH_CHECK();
         }
     }
-    if (db && dW) {  // the column sums of dY came with its transpose: one partial row per 64-row tile
+    if (db && dW && !tn) {  // the column sums of dY came with its transpose: one partial row per 64-row tile
         const int64_t ntile = mp / 64;
         float* scratch = (float*)((char*)part + align256((size_t)ntile * N * 4));
         if ((rc = launch_rows_sum(part, ntile, N, (int64_t)N, scratch, db, st)) != OV_OK) return rc;

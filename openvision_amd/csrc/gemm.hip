@@ -346,6 +346,153 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp(const GemmArgs g_in)
 }
 
 // =====================================================================================================
+// TN ping-pong kernel (weight gradients):  C[i, j] = sum_m P[m, i] * Q[m, j]  with BOTH operands stored row-major over the
+// contraction index m (dW = dY^T X: P = dY [M, N], Q = X [M, K]) -- no explicit transposes.  Same tile, phases, barriers and
+// epilogue as gemm_bf16_pp; what differs is the LDS image and the fragment reads:
+//   * a piece is 32 contraction rows x 256 columns (512-byte rows, 16 KiB), LDS-DMA'd row-major; the 16-byte chunk c of row m
+//     is stored at chunk c ^ (key(m) << 1), key(m) = (m & 3) | ((m >> 3) & 1) << 2 (applied on the per-lane SOURCE address, the
+//     DMA writes LDS lane-linearly);
+//   * an MFMA operand fragment (8 consecutive m of one column per lane) is two ds_read_b64_tr_b16: each returns, per 16-lane
+//     group, a 4-row x 16-column block column-major (lane i gets column i of the four rows).  With the key above the 32 lanes of
+//     a half-wave (row groups 8g .. 8g+3 of two g) hit 32 distinct bank pairs: conflict-free.
+// blockIdx.y = split-K range z over the contraction rows [z * chunk, min(Mc, (z + 1) * chunk)); partials are bf16, summed in
+// fp32 by the caller -- the same products in the same order as the transposed path (bitwise the same results).
+// GemmArgs reuse: A = P (lda), W = Q (ldw), M = columns of P (output rows), N = columns of Q (output columns), K = Mc
+// (contraction rows, % 64 == 0), batch_a = chunk (rows, % 64 == 0), batch_c = elements between partial outputs.
+__device__ __forceinline__ int tn_key(int m) { return (m & 3) | (((m >> 3) & 1) << 2); }
+
+template <int OFF>
+__device__ __forceinline__ u32x2_t tn_tr_read(unsigned addr) {
+    u32x2_t v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+__device__ __forceinline__ bf16x8_t tn_join(u32x2_t a, u32x2_t b) {
+    const u32x4_t w = {a[0], a[1], b[0], b[1]};
+    return __builtin_bit_cast(bf16x8_t, w);
+}
+
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_tn(const GemmArgs g_in) {
+    __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
+    GemmArgs g = g_in;
+    const int64_t kbeg = (int64_t)blockIdx.y * g.batch_a;
+    int64_t kend = kbeg + g.batch_a;
+    if (kend > g.K) kend = g.K;
+    const int nt = (int)((kend - kbeg) / BK);                       // >= 1 (launcher)
+    g.C += (int64_t)blockIdx.y * g.batch_c;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int nwg = g.tiles_m * g.tiles_n;
+    const int bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    const int tm = wgid / g.tiles_n, tn = wgid - tm * g.tiles_n;
+    const int64_t m0 = (int64_t)tm * BM;                            // first column of P = first output row
+    const int n0 = tn * BN;                                         // first column of Q = first output column
+
+    // staging: DMA i (0, 1) of a piece fills LDS chunk q = i*512 + tid = row q >> 5 (0..31), stored chunk q & 31
+    const ov_bf16* psrc[2];
+    const ov_bf16* qsrc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int mr = i * 16 + (tid >> 5);
+        const int c = (tid & 31) ^ (tn_key(mr) << 1);               // source chunk of the stored position
+        int64_t pc = m0 + c * 8;
+        pc = pc + 8 <= g.M ? pc : g.M - 8;                           // columns past the matrix: any valid chunk (never stored)
+        int qc = n0 + c * 8;
+        qc = qc + 8 <= g.N ? qc : g.N - 8;
+        psrc[i] = g.A + (kbeg + mr) * g.lda + pc;
+        qsrc[i] = g.W + (kbeg + mr) * g.ldw + qc;
+    }
+    const int64_t pstep = 32 * g.lda, qstep = 32 * g.ldw;           // half a K-tile of contraction rows
+    char* const sbase = smem + wave * 1024;
+    auto stage_piece = [&](int buf, int j, int kt) {               // piece j of K-tile kt -> buffer buf
+        char* dst = sbase + buf * STAGE_BYTES + j * PIECE_BYTES;
+        const int64_t h = 2 * kt + (j >> 1);
+        if (j & 1) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(qsrc[0] + h * qstep), (lptr_t)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(qsrc[1] + h * qstep), (lptr_t)(dst + 8192), 16, 0, 0);
+        } else {
+            __builtin_amdgcn_global_load_lds((gptr_t)(psrc[0] + h * pstep), (lptr_t)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(psrc[1] + h * pstep), (lptr_t)(dst + 8192), 16, 0, 0);
+        }
+    };
+
+    // fragment addressing: lane (g4 = lane >> 4, q = (lane & 15) >> 2, p = lane & 3) supplies block row q, columns 4p..4p+3
+    const int wm = wave >> 2, wn = wave & 3;
+    const int g4 = lane >> 4, fq4 = (lane & 15) >> 2, fp = lane & 3;
+    const int mrow = 8 * g4 + fq4;                                  // first read: rows 8 g4 .. + 3; second read: + 4 (same key)
+    const int key = tn_key(mrow);
+    const unsigned lbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    // block b of 16 columns inside the wave's range sits at chunk pair ((range_first_pair + b) ^ key): XOR on byte-offset bits 5-7
+    const unsigned a_lane = lbase + mrow * 512 + wm * 256 + (key << 5) + (fp >> 1) * 16 + (fp & 1) * 8;
+    const unsigned w_lane = lbase + PIECE_BYTES + mrow * 512 + (((wn * 4) ^ key) << 5) + (fp >> 1) * 16 + (fp & 1) * 8;
+
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int j = 0; j < 4; ++j) stage_piece(0, j, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();                     // stagger the lower wave group by one interval
+
+    u32x2_t wr[8], ar[8];                                          // 4 W-role / 4 A-role fragments, two transposed reads each
+    for (int t = 0; t < nt; ++t) {
+        const unsigned soff = (unsigned)((t & 1) * STAGE_BYTES);
+        const bool more = (t + 1 < nt);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int kh = p >> 1, mh = p & 1;
+            const unsigned po = soff + kh * (2 * PIECE_BYTES);
+            if (mh == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned ad = (w_lane + po) ^ (unsigned)(j << 5);
+                    wr[2 * j] = tn_tr_read<0>(ad);
+                    wr[2 * j + 1] = tn_tr_read<2048>(ad);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned ad = (a_lane + po) ^ (unsigned)((mh * 4 + i) << 5);
+                ar[2 * i] = tn_tr_read<0>(ad);
+                ar[2 * i + 1] = tn_tr_read<2048>(ad);
+            }
+            if (more) stage_piece((t + 1) & 1, p, t + 1);
+            if (p & 1) {
+                if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(wr[0]), "+v"(wr[1]), "+v"(wr[2]), "+v"(wr[3]), "+v"(wr[4]), "+v"(wr[5]), "+v"(wr[6]), "+v"(wr[7]),
+                           "+v"(ar[0]), "+v"(ar[1]), "+v"(ar[2]), "+v"(ar[3]), "+v"(ar[4]), "+v"(ar[5]), "+v"(ar[6]), "+v"(ar[7]));
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[mh * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tn_join(wr[2 * j], wr[2 * j + 1]),
+                                                                                 tn_join(ar[2 * i], ar[2 * i + 1]), acc[mh * 4 + i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();                     // re-align the two wave groups
+    gemm_epilogue<OV_EPI_BIAS>(g, acc, smem, m0, n0, wave, lane);
+}
+
+// =====================================================================================================
 // Persistent ping-pong kernel (default).  One workgroup per CU walks a static, XCD-contiguous list of output tiles.
 // On top of the ping-pong main loop above:
 //   * the LAST K-tile of a tile stages K-tile 0 of the NEXT tile into the free LDS buffer, and the epilogue opens by
@@ -1080,6 +1227,27 @@ extern "C" int ov_gemm_batched(const ov_bf16* A, int64_t lda, int64_t stride_a, 
                (int)tiles_n, stride_a, stride_w, stride_c, 0, 1, 0};
     hipLaunchKernelGGL(gemm_bf16_pp<OV_EPI_BIAS>, dim3((unsigned)(tiles_m * tiles_n), (unsigned)batch), dim3(NTHREADS), 0,
                        (hipStream_t)stream, a);
+    OV_LAUNCH_CHECK();
+    return OV_OK;
+}
+
+// `batch` split-K partials of C = P^T Q (both operands row-major over the contraction rows): partial z contracts rows
+// [z * chunk, min(Mc, (z + 1) * chunk)) into C + z * stride_c (bf16 [NI, NJ], no bias).  Mc % 64 == 0, chunk % 64 == 0, NI % 8 == 0,
+// NJ % 8 == 0, ldp / ldq / ldc % 8 == 0.  The weight-gradient product of ov_linear_backward without explicit transposes.
+extern "C" int ov_gemm_tn_batched(const ov_bf16* P, int64_t ldp, const ov_bf16* Q, int64_t ldq, ov_bf16* C, int64_t ldc, int64_t stride_c,
+                                  int64_t Mc, int NI, int NJ, int64_t chunk, int batch, ov_stream_t stream) {
+    if (!P || !Q || !C || Mc <= 0 || NI <= 0 || NJ <= 0 || chunk <= 0 || batch <= 0 || batch > 65535) return OV_ERR_INVALID;
+    if (Mc % BK || chunk % BK || NI % 8 || NJ % 8 || ldp % 8 || ldq % 8 || ldc % 8 || stride_c % 8) return OV_ERR_UNSUPPORTED;
+    if (ldp < NI || ldq < NJ || ldc < NJ || (int64_t)(batch - 1) * chunk >= Mc || (int64_t)batch * chunk < Mc) return OV_ERR_INVALID;
+    if (((uintptr_t)P | (uintptr_t)Q | (uintptr_t)C) & 15) return OV_ERR_INVALID;
+    const int64_t tiles_m = (NI + BM - 1) / BM, tiles_n = (NJ + BN - 1) / BN;
+    if (tiles_m * tiles_n > 0x7fffffffLL) return OV_ERR_UNSUPPORTED;
+    GemmArgs a{P, Q, nullptr, C, nullptr, ldp, ldq, ldc, 0, NI, NJ, 0, (int)tiles_m, (int)tiles_n, 0, 0, 0, nullptr, nullptr, nullptr, 0, nullptr,
+               (int)tiles_n, chunk, 0, stride_c, 0, 1, 0};
+    a.K = 0;                    // (int field: the contraction length does not fit the struct's K for huge M; carried below)
+    if (Mc > 0x7fffffffLL) return OV_ERR_UNSUPPORTED;
+    a.K = (int)Mc;
+    hipLaunchKernelGGL(gemm_bf16_pp_tn, dim3((unsigned)(tiles_m * tiles_n), (unsigned)batch), dim3(NTHREADS), 0, (hipStream_t)stream, a);
     OV_LAUNCH_CHECK();
     return OV_OK;
 }

@@ -222,3 +222,15 @@ def attention_backward(qkv, out, dout, B, L, H, hd=64):
     check(lib.ov_attention_backward(ptr(qkv), qkv.stride(0), ptr(out), out.stride(0), ptr(dout), dout.stride(0), ptr(dqkv), dqkv.stride(0),
                                     B, L, H, hd, hd ** -0.5, ptr(ws), nb, stream_ptr()), "ov_attention_backward")
     return dqkv
+
+
+def gemm_tn_batched(p, q, chunk):
+    """ov_gemm_tn_batched: partials [batch, NI, NJ] bf16 of P^T Q over row ranges of `chunk` contraction rows."""
+    lib = _lib.load()
+    mc, ni = p.shape
+    nj = q.shape[1]
+    batch = (mc + chunk - 1) // chunk
+    out = torch.empty(batch, ni, nj, dtype=torch.bfloat16, device=p.device)
+    check(lib.ov_gemm_tn_batched(ptr(p), p.stride(0), ptr(q), q.stride(0), ptr(out), nj, ni * nj, mc, ni, nj, chunk, batch, stream_ptr()),
+          "ov_gemm_tn_batched")
+    return out

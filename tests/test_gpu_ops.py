@@ -626,3 +626,26 @@ def test_attention_fp8_output(B, L, H_):
     sc = 2.0 * amax / 448.0
     deq = o8.view(torch.float8_e4m3fn).float() * sc
     assert ((deq - ref).abs() <= ref.abs() * 0.075 + sc * 2.0 ** -9 * 1.01 + 1e-6).all()
+
+
+@pytest.mark.parametrize("Mc,NI,NJ,chunk", [(256, 256, 256, 256), (640, 192, 320, 256), (8192, 1024, 1024, 2048), (4096, 3072, 768, 1024),
+                                            (65792, 1024, 1024, 8256)])
+def test_gemm_tn_matches_transposed_operands(Mc, NI, NJ, chunk):
+    """ov_gemm_tn_batched (C = P^T Q straight from the row-major operands, transposing LDS reads) against (a) fp32 torch per split-K
+    range and (b) the explicit-transpose route it replaces in ov_linear_backward (ov_transpose_bf16 + ov_gemm_batched): the same
+    products accumulated in the same order, so (b) must match BIT FOR BIT."""
+    g = torch.Generator().manual_seed(Mc + NI)
+    p = (torch.randn(Mc, NI, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+    q = (torch.randn(Mc, NJ, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+    got = H.gemm_tn_batched(p, q, chunk)
+    batch = got.shape[0]
+    lib = H._lib.load()
+    pt, qt = H.transpose(p), H.transpose(q)                       # [NI, Mc], [NJ, Mc] (Mc % 64 == 0: no padding)
+    ref2 = torch.empty_like(got)
+    for z in range(batch):
+        k0, k1 = z * chunk, min(Mc, (z + 1) * chunk)
+        want = p[k0:k1].float().T @ q[k0:k1].float()
+        err = (got[z].float() - want).abs().max().item()
+        assert err < 0.02 * (k1 - k0) ** 0.5 * 0.25 + 0.05, (z, err)
+        ref2[z] = H.gemm(pt[:, k0:k1], qt[:, k0:k1], None, epi=0)
+    assert torch.equal(got, ref2)
