@@ -257,7 +257,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_rows(const ov_bf16* __restr
 
 // d gelu / d a.  erf form: Phi(a) + a phi(a), Phi through the same A&S 7.1.26 erfc as the forward epilogue's reference form;
 // tanh form: 0.5 (1 + t) + 0.5 a (1 - t^2) u'(a), t = tanh(u), u = sqrt(2/pi) (a + 0.044715 a^3).
-__device__ __forceinline__ float gelu_erf_grad(float a) {
+// d/da gelu(a) and gelu(a) from ONE evaluation of the shared pieces (one v_rcp + one v_exp per element: the kernel is VALU-bound on
+// the quarter-rate transcendentals, and the backward needs both the gradient factor and, when the activation is not kept, h itself):
+//   erf form : Phi(a) from erfc(|a| / sqrt 2) = poly(t) exp(-a^2 / 2) (A&S 7.1.26),  gelu' = Phi + a phi(a),  gelu = a Phi
+//   tanh form: sg = sigmoid(2u), u = sqrt(2/pi) (a + 0.044715 a^3),  gelu' = sg + 2 a sg (1 - sg) u',  gelu = a sg
+__device__ __forceinline__ void gelu_erf_both(float a, float& grad, float& h) {
     const float z = fabsf(a) * 0.70710678118654752440f;
     const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
     float p = fmaf(t, 1.061405429f, -1.453152027f);
@@ -268,14 +272,16 @@ __device__ __forceinline__ float gelu_erf_grad(float a) {
     const float ex = __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);      // exp(-a^2 / 2)
     const float half_erfc = 0.5f * p * ex;
     const float Phi = a >= 0.f ? 1.0f - half_erfc : half_erfc;
-    return fmaf(a * 0.3989422804014327f, ex, Phi);
+    grad = fmaf(a * 0.3989422804014327f, ex, Phi);
+    h = a * Phi;
 }
-__device__ __forceinline__ float gelu_tanh_grad(float a) {
+__device__ __forceinline__ void gelu_tanh_both(float a, float& grad, float& h) {
     const float a2 = a * a;
     const float u = 0.7978845608028654f * a * fmaf(0.044715f, a2, 1.0f);
     const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * u));   // sigmoid(2u) = (1 + tanh u) / 2
     const float du = 0.7978845608028654f * fmaf(3.0f * 0.044715f, a2, 1.0f);
-    return fmaf(2.0f * a * sg * (1.0f - sg), du, sg);              // 0.5 (1 - t^2) = 2 sg (1 - sg)
+    grad = fmaf(2.0f * a * sg * (1.0f - sg), du, sg);              // 0.5 (1 - t^2) = 2 sg (1 - sg)
+    h = a * sg;
 }
 
 template <bool TANH>
@@ -291,10 +297,11 @@ __global__ __launch_bounds__(256) void gelu_bwd(const ov_bf16* a, int64_t lda, c
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float a0 = bf16lo_to_f32(av[e]), a1 = bf16hi_to_f32(av[e]);
-            const float g0 = TANH ? gelu_tanh_grad(a0) : gelu_erf_grad(a0);
-            const float g1 = TANH ? gelu_tanh_grad(a1) : gelu_erf_grad(a1);
+            float g0, g1, h0, h1;
+            if (TANH) { gelu_tanh_both(a0, g0, h0); gelu_tanh_both(a1, g1, h1); }
+            else { gelu_erf_both(a0, g0, h0); gelu_erf_both(a1, g1, h1); }
             o[e] = pack_bf16x2(bf16lo_to_f32(dv[e]) * g0, bf16hi_to_f32(dv[e]) * g1);
-            ho[e] = TANH ? pack_bf16x2(gelu_tanh_f(a0), gelu_tanh_f(a1)) : pack_bf16x2(gelu_erf_f(a0), gelu_erf_f(a1));
+            ho[e] = pack_bf16x2(h0, h1);
         }
         *(u32x4_t*)(da + r * ldda + c) = o;
         if (h_out != nullptr) *(u32x4_t*)(h_out + r * ldh + c) = ho;
