@@ -107,6 +107,12 @@ int ov_gemm_tn_batched(const ov_bf16* P, int64_t ldp, const ov_bf16* Q, int64_t 
 int ov_gemm_ln(const ov_bf16* X, int64_t ldx, const ov_bf16* Wg, int64_t ldw, const float* cvec, const float* colsum,
                const float* rowstats, ov_bf16* C, int64_t ldc, int64_t M, int N, int K, int epilogue, ov_stream_t stream);
 
+/* ov_gemm with a GELU epilogue (OV_EPI_BIAS_GELU_ERF / _TANH) that also keeps the pre-activation:
+ *   C = bf16(gelu(A W^T + bias)),  C2 = bf16(A W^T + bias)   [M, N], ld = ldc2
+ * -- the c_fc of the training forward, so that the backward does not run that product again (transformer.py:232-236). */
+int ov_gemm_keep(const ov_bf16* A, int64_t lda, const ov_bf16* W, int64_t ldw, const float* bias, ov_bf16* C, int64_t ldc,
+                 ov_bf16* C2, int64_t ldc2, int64_t M, int N, int K, int epilogue, ov_stream_t stream);
+
 /* rowstats[r] = {mean, rsqrt(var + eps)} of x[r, 0:D] (bf16 rows, fp32 two-pass statistics, biased variance). */
 int ov_rowstats(const ov_bf16* x, int64_t ldx, float* rowstats, int64_t rows, int D, float eps, ov_stream_t stream);
 
@@ -373,10 +379,13 @@ typedef struct {
     ov_bf16* fc_w;  float* fc_b;   /* [mlp, D], [mlp] */
     ov_bf16* proj_w; float* proj_b;/* [D, mlp], [D] */
 } ov_block_grads;
-typedef struct {      /* optional forward intermediates kept for the backward (all three or none) */
+typedef struct {      /* optional forward intermediates kept for the backward (the first three together or none) */
     const ov_bf16* qkv;        /* [B*L, 3D]  packed q | k | v */
     const ov_bf16* attn_out;   /* [B*L, D]   attention output before out_proj */
     const ov_bf16* x1;         /* [B*L, D]   x + attention branch */
+    const ov_bf16* fc_pre;     /* [B*L, mlp_pad]  c_fc output before GELU (ov_gemm_keep), or NULL = recomputed */
+    const ov_bf16* ln1_out;    /* [B*L, D]   ln_1(x), or NULL = recomputed */
+    const ov_bf16* ln2_out;    /* [B*L, D]   ln_2(x1), or NULL = recomputed */
 } ov_block_saved;
 size_t ov_block_backward_workspace_bytes(const ov_tower_cfg* cfg, int B, int L);
 int ov_block_backward(const ov_tower_cfg* cfg, const ov_block_weights* w, const ov_bf16* x, const ov_block_saved* saved /* or NULL */,
@@ -384,8 +393,9 @@ int ov_block_backward(const ov_tower_cfg* cfg, const ov_block_weights* w, const 
                       ov_stream_t stream);
 
 /* Training-side tower entry points.  ov_tower_forward_saving = the tower forward on the caller's stream that keeps, per layer and
- * token, [x | qkv | attention out | x1] (6 D bf16; `saved` holds ov_tower_saved_bytes: 19 GB for L/14 at batch 256 — sized for the
- * 288 GB of an MI355X, so only the LayerNorm outputs and the c_fc pre-activation are recomputed).  bf16 path; the blocks must hold
+ * token, [x | qkv | attention out | x1 | ln_1 out | ln_2 out | c_fc pre-activation] (8 D + mlp_pad bf16; `saved` holds
+ * ov_tower_saved_bytes: 39 GB for L/14 at batch 256 — sized for the 288 GB of an MI355X: nothing of the forward is run a second time
+ * by the backward).  bf16 path; the blocks must hold
  * the module's own, unfolded weights.  ov_tower_backward runs ov_block_backward over the layers in reverse: dx [B*L, D] holds
  * d loss / d (tower output) on entry and d loss / d (tower input) on return; grads[layer] receives that block's parameter gradients
  * (written, not accumulated). */

@@ -34,7 +34,7 @@ class BlockGrads(C.Structure):
 
 
 class BlockSaved(C.Structure):
-    _fields_ = [(n, c_void_p) for n in ("qkv", "attn_out", "x1")]
+    _fields_ = [(n, c_void_p) for n in ("qkv", "attn_out", "x1", "fc_pre", "ln1_out", "ln2_out")]
 
 
 class BlockFp8(C.Structure):
@@ -75,6 +75,8 @@ SIGNATURES = {
                                        c_void_p]),
     "ov_gemm_ln": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int,
                            c_int, c_int, c_void_p]),
+    "ov_gemm_keep": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int,
+                             c_int, c_void_p]),
     "ov_rowstats": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_float, c_void_p]),
     "ov_attention": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "ov_im2col_patches": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

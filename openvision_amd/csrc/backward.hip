@@ -555,9 +555,9 @@ extern "C" int ov_block_backward(const ov_tower_cfg* cfg, const ov_block_weights
     const float eps = cfg->ln_eps, scale = 1.0f / sqrtf((float)hd);
     int rc;
 #define OV_TRY(call) do { if ((rc = (call)) != OV_OK) return rc; } while (0)
-    // ---- the forward's intermediates: kept by ov_tower_forward_saving (qkv, attention output, x1) or recomputed; the two LayerNorm
-    //      outputs and the c_fc pre-activation are always recomputed (the forward fuses GELU into the c_fc epilogue)
-    OV_TRY(ov_layernorm(x, OV_BF16, D, w->ln1_w, w->ln1_b, b.n1, OV_BF16, D, M, D, eps, stream));
+    // ---- the forward's intermediates: kept by ov_tower_forward_saving or recomputed here
+    if (saved && saved->ln1_out) b.n1 = const_cast<ov_bf16*>(saved->ln1_out);
+    else OV_TRY(ov_layernorm(x, OV_BF16, D, w->ln1_w, w->ln1_b, b.n1, OV_BF16, D, M, D, eps, stream));
     if (saved) {
         b.qkv = const_cast<ov_bf16*>(saved->qkv); b.o = const_cast<ov_bf16*>(saved->attn_out); b.x1 = const_cast<ov_bf16*>(saved->x1);
     } else {
@@ -565,11 +565,13 @@ extern "C" int ov_block_backward(const ov_tower_cfg* cfg, const ov_block_weights
         OV_TRY(ov_attention(b.qkv, 3 * D, b.o, D, B, L, H, hd, scale, stream));
         OV_TRY(ov_gemm(b.o, D, w->out_w, D, w->out_b, b.x1, D, M, D, D, OV_EPI_BIAS_RESIDUAL, x, D, 0, 0, 0, stream));
     }
-    OV_TRY(ov_layernorm(b.x1, OV_BF16, D, w->ln2_w, w->ln2_b, b.n2, OV_BF16, D, M, D, eps, stream));
-    OV_TRY(ov_gemm(b.n2, D, w->fc_w, D, w->fc_b, b.a, F, M, F, D, OV_EPI_BIAS, nullptr, 0, 0, 0, 0, stream));
+    if (saved && saved->ln2_out) b.n2 = const_cast<ov_bf16*>(saved->ln2_out);
+    else OV_TRY(ov_layernorm(b.x1, OV_BF16, D, w->ln2_w, w->ln2_b, b.n2, OV_BF16, D, M, D, eps, stream));
+    const ov_bf16* pre = (saved && saved->fc_pre) ? saved->fc_pre : b.a;
+    if (pre == b.a) OV_TRY(ov_gemm(b.n2, D, w->fc_w, D, w->fc_b, b.a, F, M, F, D, OV_EPI_BIAS, nullptr, 0, 0, 0, 0, stream));
     // ---- MLP branch: y = x1 + c_proj(gelu(a))
     OV_TRY(ov_linear_backward(dy, D, nullptr, 0, w->proj_w, F, M, D, F, b.dh, F, nullptr, 0, nullptr, b.lin, b.lin_bytes, stream));      // dh = dy Wproj
-    OV_TRY(ov_gelu_backward(b.a, F, b.dh, F, b.dh, F, b.a, F, M, F, cfg->gelu_tanh, stream));                                          // dh -> da, a -> gelu(a), in place
+    OV_TRY(ov_gelu_backward(pre, F, b.dh, F, b.dh, F, b.a, F, M, F, cfg->gelu_tanh, stream));                                          // dh -> da (in place), b.a = gelu(a)
     OV_TRY(ov_linear_backward(dy, D, b.a, F, w->proj_w, F, M, D, F, nullptr, 0, g->proj_w, F, g->proj_b, b.lin, b.lin_bytes, stream));
     OV_TRY(ov_linear_backward(b.dh, F, b.n2, D, w->fc_w, D, M, F, D, b.t1, D, g->fc_w, D, g->fc_b, b.lin, b.lin_bytes, stream));        // t1 = d ln_2 out
     OV_TRY(ov_layernorm_backward(b.x1, D, w->ln2_w, b.t1, D, dy, D, b.dx1, D, g->ln2_w, g->ln2_b, M, D, eps, b.ln, b.ln_bytes, stream)); // dx1 = dy + ...

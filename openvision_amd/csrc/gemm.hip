@@ -41,6 +41,7 @@ struct GemmArgs {
     int64_t batch_a, batch_w, batch_c;   // gemm_bf16_pp with gridDim.y > 1: element strides of A, W, C per batch entry (split-K partials)
     int stagger, stagger_classes;        // persistent kernel: start delay (shader cycles) per class (bid >> 3) % classes (0 = off)
     int epi_prio;                        // persistent kernel: n > 0: waves 4-7 (the arbitration losers) run epilogue passes < n at s_setprio 1
+    ov_bf16* C2; int64_t ldc2;           // ov_gemm_keep: second output = the GELU epilogue's pre-activation (acc + bias), bf16
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -522,7 +523,7 @@ constexpr int SMEM_PERSIST = IMG_OFF + 8 * 2048;     // 152 KiB of the CU's 160 
 // `g.out_group ? m + m / g.out_group + 1 : m` and computes the software division on every store), and row pointers are one
 // 64-bit multiply per lane, stepped by whole rows, instead of one per store -- ~250 of the ~500 (bias) to ~1200 (residual) VALU
 // instructions of the epilogue were such address arithmetic.
-template <int EPI, bool FOLD, bool MAPPED>
+template <int EPI, bool FOLD, bool MAPPED, bool KEEP = false>
 __device__ __forceinline__ void epilogue_stream(const GemmArgs& g, f32x4_t (&acc)[8][4], const char* prm,
                                                 int64_t m0, int n0, int wave, int lane, bool edge, unsigned long long* wst) {
     const int wm = wave >> 2, wn = wave & 3;
@@ -538,6 +539,7 @@ __device__ __forceinline__ void epilogue_stream(const GemmArgs& g, f32x4_t (&acc
     // !MAPPED: this lane's row of pass 0 (clamped for the residual read: rows past M re-read row M - 1, never stored)
     const int64_t mbase = m0 + wm * 128 + fr;
     ov_bf16* const cbase = !MAPPED ? g.C + mbase * g.ldc + n_lo : nullptr;
+    ov_bf16* const cbase2 = KEEP ? g.C2 + mbase * g.ldc2 + n_lo : nullptr;
     auto load_resid = [&](int i) {      // inline asm: the waits below are counted by hand (hipcc would use vmcnt(0))
         if (!MAPPED) {
             int64_t m = mbase + i * 16;
@@ -628,7 +630,7 @@ __device__ __forceinline__ void epilogue_stream(const GemmArgs& g, f32x4_t (&acc
             nm = f32x2_t{-stq[i][0], -stq[i][0]};
             rs = f32x2_t{stq[i][1], stq[i][1]};
         }
-        u32x2_t pk[4];
+        u32x2_t pk[4], pk2[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             f32x2_t v01 = f32x2_t{acc[i][j][0], acc[i][j][1]};
@@ -642,9 +644,20 @@ __device__ __forceinline__ void epilogue_stream(const GemmArgs& g, f32x4_t (&acc
                 v01 += f32x2_t{bv[j][0], bv[j][1]};
                 v23 += f32x2_t{bv[j][2], bv[j][3]};
             }
+            if (KEEP) pk2[j] = u32x2_t{pack_bf16x2(v01[0], v01[1]), pack_bf16x2(v23[0], v23[1])};
             if (EPI == OV_EPI_BIAS_GELU_ERF) gelu_erf_f2x2(v01, v23);
             if (EPI == OV_EPI_BIAS_GELU_TANH) { v01 = gelu_tanh_f2(v01); v23 = gelu_tanh_f2(v23); }
             pk[j] = u32x2_t{pack_bf16x2(v01[0], v01[1]), pack_bf16x2(v23[0], v23[1])};
+        }
+        if (KEEP) {          // the pre-activation rows, same lane -> chunk map as the output (never MAPPED, never residual)
+            const unsigned m = (unsigned)m0 + wm * 128 + i * 16 + fr;
+            ov_bf16* dst2 = cbase2 + (int64_t)(i * 16) * g.ldc2;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const u32x2_t s0 = __builtin_amdgcn_permlane16_swap(pk2[2 * h][0], pk2[2 * h + 1][0], false, false);
+                const u32x2_t s1 = __builtin_amdgcn_permlane16_swap(pk2[2 * h][1], pk2[2 * h + 1][1], false, false);
+                if (m < (unsigned)g.M && (h ? ncol1 : ncol0)) *(u32x4_t*)(dst2 + h * 32) = u32x4_t{s0[0], s1[0], s0[1], s1[1]};
+            }
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -812,7 +825,7 @@ __device__ __forceinline__ void epilogue_stream_lds(const GemmArgs& g, f32x4_t (
 template <int V> struct IntC { static constexpr int value = V; };
 struct TileSrc { const ov_bf16* a0; const ov_bf16* a1; const ov_bf16* w0; const ov_bf16* w1; };   // per-lane staging sources
 
-template <int EPI, bool FOLD, bool DIRECT, bool MAPPED>
+template <int EPI, bool FOLD, bool DIRECT, bool MAPPED, bool KEEP = false>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist(const GemmArgs g) {
     __shared__ __attribute__((aligned(16))) char smem[DIRECT ? IMG_OFF : SMEM_PERSIST];
     const int tid = threadIdx.x;
@@ -1056,7 +1069,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist(const GemmArgs 
         const bool edge = (m0 + BM > g.M) || (n0 + BN > g.N);      // an edge tile issues fewer than 16 stores per wave
         if (wst != nullptr && lane == 0) wst[1] = __builtin_amdgcn_s_memtime();
         if (g.epi_prio && wm == 1) __builtin_amdgcn_s_setprio(1);
-        if (DIRECT) epilogue_stream<EPI, FOLD, MAPPED>(g, acc, smem + PRM_OFF + pslot * 4096, m0, n0, wave, lane, edge, wst);
+        if (DIRECT) epilogue_stream<EPI, FOLD, MAPPED, KEEP>(g, acc, smem + PRM_OFF + pslot * 4096, m0, n0, wave, lane, edge, wst);
         else epilogue_stream_lds<EPI, FOLD, MAPPED>(g, acc, smem + IMG_OFF + wave * 2048, smem + PRM_OFF + pslot * 4096, m0, n0, wave, lane, edge, wst);
         if (g.epi_prio && wm == 1) __builtin_amdgcn_s_setprio(0);
         stamp(3);
@@ -1079,6 +1092,8 @@ int num_cus() { return ov_num_cus(); }
 
 thread_local const float* g_colsum = nullptr;      // set by ov_gemm_ln around its call into ov_gemm
 thread_local const float* g_rowstats = nullptr;
+thread_local ov_bf16* g_keep = nullptr;            // set by ov_gemm_keep around its call into ov_gemm
+thread_local int64_t g_ldkeep = 0;
 unsigned long long* g_stamps = nullptr;
 unsigned long long* g_wstamps = nullptr;
 int g_stamp_slots = 0;
@@ -1145,6 +1160,16 @@ int launch(GemmArgs a, hipStream_t st) {
     if (var == 0 && (nwg < min_persist || a.K < 3 * BK)) var = 2;
     // row maps (the patch embedding's GEMM) exist in the persistent kernel for the bias and residual epilogues only
     if (var == 0 && (a.out_group != 0 || a.resid_mod != 0) && EPI != OV_EPI_BIAS && EPI != OV_EPI_BIAS_RESIDUAL) var = 2;
+    if (a.C2 != nullptr && var != 0) {
+        // grids below the persistent kernel's threshold (the tower's tail images): the pre-activation from a second, bias-only
+        // product -- the same fp32 accumulators and the same rounding as the fused form
+        GemmArgs b = a;
+        b.C = a.C2; b.ldc = a.ldc2; b.C2 = nullptr;
+        hipLaunchKernelGGL(gemm_bf16_pp<OV_EPI_BIAS>, dim3(nwg), dim3(NTHREADS), 0, st, b);
+        OV_LAUNCH_CHECK();
+        a.C2 = nullptr;
+        var = 2;
+    }
     if (var == 1) {
         hipLaunchKernelGGL(gemm_bf16_256x256<EPI>, dim3(nwg), dim3(NTHREADS), 0, st, a);
     } else if (var == 2) {
@@ -1170,6 +1195,9 @@ int launch(GemmArgs a, hipStream_t st) {
                 if (direct0) hipLaunchKernelGGL((gemm_bf16_persist<OV_EPI_BIAS, false, true, false>), grid, blk, 0, st, a);
                 else hipLaunchKernelGGL((gemm_bf16_persist<OV_EPI_BIAS, false, false, false>), grid, blk, 0, st, a);
             }
+        } else if (a.C2 != nullptr) {             // ov_gemm_keep (GELU epilogues, unfolded weights: checked by the caller)
+            constexpr int E = (EPI == OV_EPI_BIAS_GELU_ERF || EPI == OV_EPI_BIAS_GELU_TANH) ? EPI : OV_EPI_BIAS_GELU_ERF;
+            hipLaunchKernelGGL((gemm_bf16_persist<E, false, true, false, true>), grid, blk, 0, st, a);
         } else if (CAN_FOLD && a.colsum != nullptr) {
             hipLaunchKernelGGL((gemm_bf16_persist<EPI, CAN_FOLD, true, false>), grid, blk, 0, st, a);
         } else if (EPI == OV_EPI_BIAS_RESIDUAL && mapped) {
@@ -1202,7 +1230,7 @@ extern "C" int ov_gemm(const ov_bf16* A, int64_t lda, const ov_bf16* W, int64_t 
     if (tiles_m * tiles_n > 0x7fffffffLL || M > 0x7fff0000LL) return OV_ERR_UNSUPPORTED;    // 32-bit row indices in the kernels
     GemmArgs a{A, W, bias, C, R, lda, ldw, ldc, ldr, M, N, K, (int)tiles_m, (int)tiles_n,
                out_group, resid_mod, resid_off, g_colsum, g_rowstats, g_stamps, g_stamp_slots, g_wstamps, gemm_ngroup((int)tiles_m, (int)tiles_n, K), 0, 0, 0,
-               gemm_stagger(K), gemm_stagger_classes(), gemm_epi_prio()};
+               gemm_stagger(K), gemm_stagger_classes(), gemm_epi_prio(), g_keep, g_ldkeep};
     hipStream_t st = (hipStream_t)stream;
     switch (epilogue) {
         case OV_EPI_BIAS: return launch<OV_EPI_BIAS>(a, st);
@@ -1211,6 +1239,18 @@ extern "C" int ov_gemm(const ov_bf16* A, int64_t lda, const ov_bf16* W, int64_t 
         case OV_EPI_BIAS_RESIDUAL: return launch<OV_EPI_BIAS_RESIDUAL>(a, st);
         default: return OV_ERR_INVALID;
     }
+}
+
+// ov_gemm with a GELU epilogue that also keeps the pre-activation: C = gelu(A W^T + bias), C2 = bf16(A W^T + bias) -- the training
+// forward's c_fc, so that the backward does not run this product a second time.
+extern "C" int ov_gemm_keep(const ov_bf16* A, int64_t lda, const ov_bf16* W, int64_t ldw, const float* bias, ov_bf16* C, int64_t ldc,
+                            ov_bf16* C2, int64_t ldc2, int64_t M, int N, int K, int epilogue, ov_stream_t stream) {
+    if (epilogue != OV_EPI_BIAS_GELU_ERF && epilogue != OV_EPI_BIAS_GELU_TANH) return OV_ERR_INVALID;
+    if (!C2 || ldc2 % 8 || ldc2 < N || ((uintptr_t)C2 & 15)) return OV_ERR_INVALID;
+    g_keep = C2; g_ldkeep = ldc2;
+    const int rc = ov_gemm(A, lda, W, ldw, bias, C, ldc, M, N, K, epilogue, nullptr, 0, 0, 0, 0, stream);
+    g_keep = nullptr; g_ldkeep = 0;
+    return rc;
 }
 
 // `batch` independent products C_z = A_z . W_z^T (bf16 out, no bias) in ONE launch of the non-persistent kernel, blockIdx.y = z.

@@ -31,6 +31,18 @@ def gemm(a, w, bias=None, epi=0, resid=None, out=None, out_group=0, resid_mod=0,
     return out
 
 
+def gemm_keep(a, w, bias, epi, ldc=None, ldc2=None):
+    """C = gelu(a w^T + bias), C2 = a w^T + bias (both bf16) from one launch: ov_gemm_keep."""
+    lib = _lib.load()
+    m, k = a.shape
+    n = w.shape[0]
+    out = torch.zeros(m, ldc or n, dtype=torch.bfloat16, device=a.device)
+    pre = torch.zeros(m, ldc2 or n, dtype=torch.bfloat16, device=a.device)
+    check(lib.ov_gemm_keep(ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(out), out.stride(0), ptr(pre), pre.stride(0),
+                           m, n, k, epi, stream_ptr()))
+    return out, pre
+
+
 def attention(qkv, B, L, H, hd=64):
     lib = _lib.load()
     out = torch.empty(B * L, H * hd, dtype=torch.bfloat16, device=qkv.device)

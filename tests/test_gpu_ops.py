@@ -60,6 +60,17 @@ def test_gemm_gelu(epi, tanh):
     np.testing.assert_allclose(c.numpy(), ref.numpy(), rtol=1e-2, atol=1e-2)
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(333, 768, 192, 1), (257 * 70 + 9, 4096, 1024, 1), (4100, 4304, 1152, 2), (65792, 1024, 256, 1)])
+def test_gemm_keep_pre_activation_is_the_bias_gemm_and_output_the_gelu_gemm(M, N, K, epi):
+    """ov_gemm_keep (the training forward's c_fc): both outputs bitwise equal to the two single-output launches, on grids below the
+    persistent kernel's threshold (second launch) and above it (one fused epilogue), with padded leading dimensions and ragged edges."""
+    a, w, bias = rnd(M, K, seed=10).to(torch.bfloat16).to(DEV), (rnd(N, K, seed=11) / K ** 0.5).to(torch.bfloat16).to(DEV), rnd(N, seed=12).to(DEV)
+    out, pre = H.gemm_keep(a, w, bias, epi, ldc=N + 64, ldc2=N + 8)
+    assert torch.equal(out[:, :N], H.gemm(a, w, bias, epi=epi))
+    assert torch.equal(pre[:, :N], H.gemm(a, w, bias, epi=0))
+    assert not out[:, N:].any() and not pre[:, N:].any()
+
+
 @pytest.mark.parametrize("M,N,K,epi", [(771, 3072, 1024, 0), (300, 768, 192, 1), (65535, 1024, 1024, 0), (200, 2304, 768, 2)])
 def test_gemm_ln_fold_matches_layernorm_then_linear(M, N, K, epi):
     """ov_rowstats + ov_gemm_ln == Linear(LayerNorm(x)) (transformer.py:263-264) without materialising LN(x)."""
