@@ -96,9 +96,11 @@ int ov_gemm_batched(const ov_bf16* A, int64_t lda, int64_t stride_a, const ov_bf
 /* Split-K partials of C = P^T Q with BOTH operands row-major over the contraction rows (P [Mc, NI], Q [Mc, NJ]): partial z contracts
  * rows [z * chunk, min(Mc, (z + 1) * chunk)) into C + z * stride_c (bf16 [NI, NJ], no bias).  The weight-gradient product
  * dW = dY^T X of ov_linear_backward without explicit transposes (transposing LDS reads, ds_read_b64_tr_b16).  Mc % 64 == 0,
- * chunk % 64 == 0, (batch - 1) * chunk < Mc <= batch * chunk, NI / NJ / leading dimensions % 8 == 0. */
+ * chunk % 64 == 0, (batch - 1) * chunk < Mc <= batch * chunk, NI / NJ / leading dimensions % 8 == 0.
+ * psum (or NULL): fp32 [batch][NI], psum[z][i] = sum of P[m, i] over the rows of partial z -- the bias gradient sum_m dY[m, i] from the
+ * fragments the product already holds (one more MFMA against an all-ones operand), instead of a second pass over dY. */
 int ov_gemm_tn_batched(const ov_bf16* P, int64_t ldp, const ov_bf16* Q, int64_t ldq, ov_bf16* C, int64_t ldc, int64_t stride_c, int64_t Mc,
-                       int NI, int NJ, int64_t chunk, int batch, ov_stream_t stream);
+                       int NI, int NJ, int64_t chunk, int batch, float* psum, ov_stream_t stream);
 
 /* LayerNorm folded into the following Linear (LN(x) W^T + b without materialising LN(x)):
  *   C = epilogue( rstd[m] * (x W'^T - mean[m] * colsum[n]) + cvec[n] ),

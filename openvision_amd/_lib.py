@@ -99,7 +99,7 @@ SIGNATURES = {
     "ov_gemm_batched": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int, c_int,
                                 c_int, c_void_p]),
     "ov_gemm_tn_batched": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int64, c_int,
-                                   c_void_p]),
+                                   c_void_p, c_void_p]),
     "ov_attention_backward_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "ov_attention_backward": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int,
                                       c_float, c_void_p, c_size_t, c_void_p]),

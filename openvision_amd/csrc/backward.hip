@@ -24,7 +24,7 @@ extern "C" size_t ov_attention_backward_workspace_bytes(int B, int L, int H, int
 extern "C" int ov_gemm_batched(const ov_bf16* A, int64_t lda, int64_t stride_a, const ov_bf16* W, int64_t ldw, int64_t stride_w,
                                ov_bf16* C, int64_t ldc, int64_t stride_c, int64_t M, int N, int K, int batch, ov_stream_t stream);
 extern "C" int ov_gemm_tn_batched(const ov_bf16* P, int64_t ldp, const ov_bf16* Q, int64_t ldq, ov_bf16* C, int64_t ldc, int64_t stride_c,
-                                  int64_t Mc, int NI, int NJ, int64_t chunk, int batch, ov_stream_t stream);
+                                  int64_t Mc, int NI, int NJ, int64_t chunk, int batch, float* psum, ov_stream_t stream);
 
 namespace {
 
@@ -401,9 +401,10 @@ extern "C" int ov_linear_backward(const ov_bf16* dY, int64_t lddy, const ov_bf16
     const bool tn = dW && (M % 64 == 0) && !force_tr;
     if (dW && tn) {
         if (sp.nz == 1) {
-            if ((rc = ov_gemm_tn_batched(dY, lddy, X, ldx, dW, lddw, 0, M, N, K, sp.chunk, 1, stream)) != OV_OK) return rc;
+            if ((rc = ov_gemm_tn_batched(dY, lddy, X, ldx, dW, lddw, 0, M, N, K, sp.chunk, 1, db, stream)) != OV_OK) return rc;
         } else {
-            if ((rc = ov_gemm_tn_batched(dY, lddy, X, ldx, dWp, K, (int64_t)N * K, M, N, K, sp.chunk, sp.nz, stream)) != OV_OK) return rc;
+            if ((rc = ov_gemm_tn_batched(dY, lddy, X, ldx, dWp, K, (int64_t)N * K, M, N, K, sp.chunk, sp.nz, db ? part : nullptr, stream)) != OV_OK)
+                return rc;
             const int64_t total8 = (int64_t)N * K / 8;
             int64_t blocks = (total8 + 255) / 256;
             if (blocks > 4096) blocks = 4096;
@@ -428,7 +429,12 @@ extern "C" int ov_linear_backward(const ov_bf16* dY, int64_t lddy, const ov_bf16
             OV_LAUNCH_CHECK();
         }
     }
-    if (db && dW && !tn) {  // the column sums of dY came with its transpose: one partial row per 64-row tile
+    if (db && tn) {         // the column sums of dY came out of the TN kernel, one partial row per split (nz == 1: straight into db)
+        if (sp.nz > 1) {
+            float* scratch = (float*)((char*)part + align256((size_t)(mp / 64) * N * 4));
+            if ((rc = launch_rows_sum(part, sp.nz, N, (int64_t)N, scratch, db, st)) != OV_OK) return rc;
+        }
+    } else if (db && dW) {  // the column sums of dY came with its transpose: one partial row per 64-row tile
         const int64_t ntile = mp / 64;
         float* scratch = (float*)((char*)part + align256((size_t)ntile * N * 4));
         if ((rc = launch_rows_sum(part, ntile, N, (int64_t)N, scratch, db, st)) != OV_OK) return rc;

@@ -42,6 +42,7 @@ struct GemmArgs {
     int stagger, stagger_classes;        // persistent kernel: start delay (shader cycles) per class (bid >> 3) % classes (0 = off)
     int epi_prio;                        // persistent kernel: n > 0: waves 4-7 (the arbitration losers) run epilogue passes < n at s_setprio 1
     ov_bf16* C2; int64_t ldc2;           // ov_gemm_keep: second output = the GELU epilogue's pre-activation (acc + bias), bf16
+    float* psum;                         // gemm_bf16_pp_tn: [gridDim.y][M] column sums of P over the split's rows (NULL = off)
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -360,6 +361,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp(const GemmArgs g_in)
 // fp32 by the caller -- the same products in the same order as the transposed path (bitwise the same results).
 // GemmArgs reuse: A = P (lda), W = Q (ldw), M = columns of P (output rows), N = columns of Q (output columns), K = Mc
 // (contraction rows, % 64 == 0), batch_a = chunk (rows, % 64 == 0), batch_c = elements between partial outputs.
+// psum != NULL: the workgroups of output column tile 0 also produce the column sums of P (the bias gradient sum_m dY[m, i]) as one
+// more MFMA per phase and wave against an all-ones operand -- the P fragments are in registers anyway, so the separate pass over dY
+// (8 ms of the L/14 training step) disappears; wave wn takes fragment wn of the four, fp32 accumulators like every other product.
 __device__ __forceinline__ int tn_key(int m) { return (m & 3) | (((m >> 3) & 1) << 2); }
 
 template <int OFF>
@@ -444,6 +448,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_tn(const GemmArgs g_
     if (wm == 1) __builtin_amdgcn_s_barrier();                     // stagger the lower wave group by one interval
 
     u32x2_t wr[8], ar[8];                                          // 4 W-role / 4 A-role fragments, two transposed reads each
+    const bool colsums = g.psum != nullptr && tn == 0;             // block-uniform
+    f32x4_t accs[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+    const u32x4_t ones_w = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_w);
     for (int t = 0; t < nt; ++t) {
         const unsigned soff = (unsigned)((t & 1) * STAGE_BYTES);
         const bool more = (t + 1 < nt);
@@ -483,6 +491,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_tn(const GemmArgs g_
                 for (int j = 0; j < 4; ++j)
                     acc[mh * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tn_join(wr[2 * j], wr[2 * j + 1]),
                                                                                  tn_join(ar[2 * i], ar[2 * i + 1]), acc[mh * 4 + i][j], 0, 0, 0);
+            if (colsums) {      // D[r][c] = sum_k 1 * P[k, c]: every row of the 16 x 16 result holds the 16 column sums
+                switch (wn) {
+                    case 0: accs[mh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, tn_join(ar[0], ar[1]), accs[mh], 0, 0, 0); break;
+                    case 1: accs[mh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, tn_join(ar[2], ar[3]), accs[mh], 0, 0, 0); break;
+                    case 2: accs[mh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, tn_join(ar[4], ar[5]), accs[mh], 0, 0, 0); break;
+                    default: accs[mh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, tn_join(ar[6], ar[7]), accs[mh], 0, 0, 0); break;
+                }
+            }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
@@ -490,6 +506,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_pp_tn(const GemmArgs g_
         }
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();                     // re-align the two wave groups
+    if (colsums && lane < 16) {                                    // row 0 of the result: lane c holds the sum of column c
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh) {
+            const int64_t ni = m0 + wm * 128 + (mh * 4 + wn) * 16 + lane;
+            if (ni < g.M) g.psum[(int64_t)blockIdx.y * g.M + ni] = accs[mh][0];
+        }
+    }
     gemm_epilogue<OV_EPI_BIAS>(g, acc, smem, m0, n0, wave, lane);
 }
 
@@ -1274,8 +1297,9 @@ extern "C" int ov_gemm_batched(const ov_bf16* A, int64_t lda, int64_t stride_a, 
 // `batch` split-K partials of C = P^T Q (both operands row-major over the contraction rows): partial z contracts rows
 // [z * chunk, min(Mc, (z + 1) * chunk)) into C + z * stride_c (bf16 [NI, NJ], no bias).  Mc % 64 == 0, chunk % 64 == 0, NI % 8 == 0,
 // NJ % 8 == 0, ldp / ldq / ldc % 8 == 0.  The weight-gradient product of ov_linear_backward without explicit transposes.
+// psum (or NULL): fp32 [batch][NI], psum[z][i] = sum of P[m, i] over the rows of partial z (the bias gradient's partial sums).
 extern "C" int ov_gemm_tn_batched(const ov_bf16* P, int64_t ldp, const ov_bf16* Q, int64_t ldq, ov_bf16* C, int64_t ldc, int64_t stride_c,
-                                  int64_t Mc, int NI, int NJ, int64_t chunk, int batch, ov_stream_t stream) {
+                                  int64_t Mc, int NI, int NJ, int64_t chunk, int batch, float* psum, ov_stream_t stream) {
     if (!P || !Q || !C || Mc <= 0 || NI <= 0 || NJ <= 0 || chunk <= 0 || batch <= 0 || batch > 65535) return OV_ERR_INVALID;
     if (Mc % BK || chunk % BK || NI % 8 || NJ % 8 || ldp % 8 || ldq % 8 || ldc % 8 || stride_c % 8) return OV_ERR_UNSUPPORTED;
     if (ldp < NI || ldq < NJ || ldc < NJ || (int64_t)(batch - 1) * chunk >= Mc || (int64_t)batch * chunk < Mc) return OV_ERR_INVALID;
@@ -1287,6 +1311,7 @@ extern "C" int ov_gemm_tn_batched(const ov_bf16* P, int64_t ldp, const ov_bf16* 
     a.K = 0;                    // (int field: the contraction length does not fit the struct's K for huge M; carried below)
     if (Mc > 0x7fffffffLL) return OV_ERR_UNSUPPORTED;
     a.K = (int)Mc;
+    a.psum = psum;
     hipLaunchKernelGGL(gemm_bf16_pp_tn, dim3((unsigned)(tiles_m * tiles_n), (unsigned)batch), dim3(NTHREADS), 0, (hipStream_t)stream, a);
     OV_LAUNCH_CHECK();
     return OV_OK;

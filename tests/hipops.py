@@ -236,13 +236,15 @@ def attention_backward(qkv, out, dout, B, L, H, hd=64):
     return dqkv
 
 
-def gemm_tn_batched(p, q, chunk):
-    """ov_gemm_tn_batched: partials [batch, NI, NJ] bf16 of P^T Q over row ranges of `chunk` contraction rows."""
+def gemm_tn_batched(p, q, chunk, sums=False):
+    """ov_gemm_tn_batched: partials [batch, NI, NJ] bf16 of P^T Q over row ranges of `chunk` contraction rows
+    (sums=True: and the fp32 [batch, NI] column sums of P over the same ranges)."""
     lib = _lib.load()
     mc, ni = p.shape
     nj = q.shape[1]
     batch = (mc + chunk - 1) // chunk
     out = torch.empty(batch, ni, nj, dtype=torch.bfloat16, device=p.device)
-    check(lib.ov_gemm_tn_batched(ptr(p), p.stride(0), ptr(q), q.stride(0), ptr(out), nj, ni * nj, mc, ni, nj, chunk, batch, stream_ptr()),
-          "ov_gemm_tn_batched")
-    return out
+    ps = torch.full((batch, ni), float("nan"), dtype=torch.float32, device=p.device) if sums else None
+    check(lib.ov_gemm_tn_batched(ptr(p), p.stride(0), ptr(q), q.stride(0), ptr(out), nj, ni * nj, mc, ni, nj, chunk, batch, ptr(ps),
+                                 stream_ptr()), "ov_gemm_tn_batched")
+    return (out, ps) if sums else out

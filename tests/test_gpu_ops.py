@@ -648,9 +648,12 @@ def test_gemm_tn_matches_transposed_operands(Mc, NI, NJ, chunk):
     g = torch.Generator().manual_seed(Mc + NI)
     p = (torch.randn(Mc, NI, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
     q = (torch.randn(Mc, NJ, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
-    got = H.gemm_tn_batched(p, q, chunk)
+    got, psum = H.gemm_tn_batched(p, q, chunk, sums=True)
+    assert torch.equal(got, H.gemm_tn_batched(p, q, chunk))      # the column-sum MFMAs leave the product alone
     batch = got.shape[0]
-    lib = H._lib.load()
+    for z in range(batch):                                        # bias-gradient partials: fp32 sums of bf16 values, any order
+        want = p[z * chunk:min(Mc, (z + 1) * chunk)].double().sum(0)
+        assert (psum[z].double() - want).abs().max().item() < 1e-5 * chunk ** 0.5 * 8 + 1e-4, z
     pt, qt = H.transpose(p), H.transpose(q)                       # [NI, Mc], [NJ, Mc] (Mc % 64 == 0: no padding)
     ref2 = torch.empty_like(got)
     for z in range(batch):
