@@ -61,7 +61,9 @@ enum ov_epilogue {
     OV_EPI_BIAS = 0,                  /* C = bf16(acc + bias)                (bias may be NULL) */
     OV_EPI_BIAS_GELU_ERF = 1,         /* C = bf16(gelu_erf(acc + bias))      vision MLP, vit.py:202 */
     OV_EPI_BIAS_GELU_TANH = 2,        /* C = bf16(gelu_tanh(acc + bias))     text MLP, text_transformer.py:117 */
-    OV_EPI_BIAS_RESIDUAL = 3          /* C = bf16(bf16(acc + bias) + R)      x = x + f(x), transformer.py:263-264 */
+    OV_EPI_BIAS_RESIDUAL = 3,         /* C = bf16(bf16(acc + bias) + R)      x = x + f(x), transformer.py:263-264 */
+    OV_EPI_GELU_GRAD_ERF = 4,         /* C = bf16(bf16(acc + bias) * gelu_erf'(R))   backward through the MLP's GELU: R = the c_fc */
+    OV_EPI_GELU_GRAD_TANH = 5         /* C = bf16(bf16(acc + bias) * gelu_tanh'(R))  pre-activation (ov_gemm_keep), acc = dy Wproj */
 };
 
 int         ov_abi_version(void);
@@ -388,6 +390,8 @@ typedef struct {      /* optional forward intermediates kept for the backward (t
     const ov_bf16* fc_pre;     /* [B*L, mlp_pad]  c_fc output before GELU (ov_gemm_keep), or NULL = recomputed */
     const ov_bf16* ln1_out;    /* [B*L, D]   ln_1(x), or NULL = recomputed */
     const ov_bf16* ln2_out;    /* [B*L, D]   ln_2(x1), or NULL = recomputed */
+    const ov_bf16* fc_act;     /* [B*L, mlp_pad]  gelu(fc_pre), or NULL = recomputed; with fc_pre set too, the backward folds the GELU
+                                * derivative into the epilogue of dy Wproj (OV_EPI_GELU_GRAD_*) and runs no element-wise pass */
 } ov_block_saved;
 size_t ov_block_backward_workspace_bytes(const ov_tower_cfg* cfg, int B, int L);
 int ov_block_backward(const ov_tower_cfg* cfg, const ov_block_weights* w, const ov_bf16* x, const ov_block_saved* saved /* or NULL */,
@@ -395,8 +399,8 @@ int ov_block_backward(const ov_tower_cfg* cfg, const ov_block_weights* w, const 
                       ov_stream_t stream);
 
 /* Training-side tower entry points.  ov_tower_forward_saving = the tower forward on the caller's stream that keeps, per layer and
- * token, [x | qkv | attention out | x1 | ln_1 out | ln_2 out | c_fc pre-activation] (8 D + mlp_pad bf16; `saved` holds
- * ov_tower_saved_bytes: 39 GB for L/14 at batch 256 — sized for the 288 GB of an MI355X: nothing of the forward is run a second time
+ * token, [x | qkv | attention out | x1 | ln_1 out | ln_2 out | c_fc pre-activation | c_fc activation] (8 D + 2 mlp_pad bf16; `saved`
+ * holds ov_tower_saved_bytes: 52 GB for L/14 at batch 256 — sized for the 288 GB of an MI355X: nothing of the forward is run a second time
  * by the backward).  bf16 path; the blocks must hold
  * the module's own, unfolded weights.  ov_tower_backward runs ov_block_backward over the layers in reverse: dx [B*L, D] holds
  * d loss / d (tower output) on entry and d loss / d (tower input) on return; grads[layer] receives that block's parameter gradients

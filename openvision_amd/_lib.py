@@ -34,7 +34,7 @@ class BlockGrads(C.Structure):
 
 
 class BlockSaved(C.Structure):
-    _fields_ = [(n, c_void_p) for n in ("qkv", "attn_out", "x1", "fc_pre", "ln1_out", "ln2_out")]
+    _fields_ = [(n, c_void_p) for n in ("qkv", "attn_out", "x1", "fc_pre", "ln1_out", "ln2_out", "fc_act")]
 
 
 class BlockFp8(C.Structure):

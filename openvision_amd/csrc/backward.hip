@@ -369,9 +369,11 @@ extern "C" size_t ov_linear_backward_workspace_bytes(int64_t M, int N, int K) {
            align256((size_t)RS_SPLIT * N * 4);
 }
 
-extern "C" int ov_linear_backward(const ov_bf16* dY, int64_t lddy, const ov_bf16* X, int64_t ldx, const ov_bf16* W, int64_t ldw,
-                                  int64_t M, int N, int K, ov_bf16* dX, int64_t lddx, ov_bf16* dW, int64_t lddw, float* db,
-                                  void* workspace, size_t workspace_bytes, ov_stream_t stream) {
+// dx_epi / dx_r: the epilogue of the dX product and its second operand [M, K] (ov_block_backward: the GELU derivative at the c_fc
+// pre-activation multiplies dy Wproj right there, OV_EPI_GELU_GRAD_*); OV_EPI_BIAS / NULL = plain dX
+static int linear_backward(const ov_bf16* dY, int64_t lddy, const ov_bf16* X, int64_t ldx, const ov_bf16* W, int64_t ldw,
+                           int64_t M, int N, int K, ov_bf16* dX, int64_t lddx, ov_bf16* dW, int64_t lddw, float* db,
+                           void* workspace, size_t workspace_bytes, ov_stream_t stream, int dx_epi, const ov_bf16* dx_r, int64_t lddxr) {
     if (!dY || !W || !workspace || M <= 0 || N <= 0 || K <= 0) return OV_ERR_INVALID;
     if ((!dX && !dW && !db) || (dW && !X)) return OV_ERR_INVALID;
     if (N % 64 || K % 64 || lddy % 8 || ldw % 8 || lddy < N || ldw < K || (X && (ldx % 8 || ldx < K))) return OV_ERR_UNSUPPORTED;
@@ -391,7 +393,7 @@ extern "C" int ov_linear_backward(const ov_bf16* dY, int64_t lddy, const ov_bf16
     int rc;
     if (dX) {       // dX[M, K] = dY[M, N] . W[N, K]  =  ov_gemm(A = dY, "W" = W^T [K, N]) contracting over N
         if ((rc = launch_transpose(W, ldw, N, N, K, Wt, N, st)) != OV_OK) return rc;
-        if ((rc = ov_gemm(dY, lddy, Wt, N, nullptr, dX, lddx, M, K, N, OV_EPI_BIAS, nullptr, 0, 0, 0, 0, stream)) != OV_OK) return rc;
+        if ((rc = ov_gemm(dY, lddy, Wt, N, nullptr, dX, lddx, M, K, N, dx_epi, dx_r, lddxr, 0, 0, 0, stream)) != OV_OK) return rc;
     }
     // dW = dY^T X straight from the row-major operands (transposing LDS reads) when the row count is a multiple of the 64-row
     // K-tile (B * L of every tower is: 257 * 256, 80 * 256, ...); OVHIP_DW_TRANSPOSE=1 forces the explicit-transpose route.  Both
@@ -448,6 +450,12 @@ extern "C" int ov_linear_backward(const ov_bf16* dY, int64_t lddy, const ov_bf16
         if ((rc = launch_rows_sum(part, nchunk, N, (int64_t)N, scratch, db, st)) != OV_OK) return rc;
     }
     return OV_OK;
+}
+
+extern "C" int ov_linear_backward(const ov_bf16* dY, int64_t lddy, const ov_bf16* X, int64_t ldx, const ov_bf16* W, int64_t ldw,
+                                  int64_t M, int N, int K, ov_bf16* dX, int64_t lddx, ov_bf16* dW, int64_t lddw, float* db,
+                                  void* workspace, size_t workspace_bytes, ov_stream_t stream) {
+    return linear_backward(dY, lddy, X, ldx, W, ldw, M, N, K, dX, lddx, dW, lddw, db, workspace, workspace_bytes, stream, OV_EPI_BIAS, nullptr, 0);
 }
 
 namespace {
@@ -576,9 +584,16 @@ extern "C" int ov_block_backward(const ov_tower_cfg* cfg, const ov_block_weights
     const ov_bf16* pre = (saved && saved->fc_pre) ? saved->fc_pre : b.a;
     if (pre == b.a) OV_TRY(ov_gemm(b.n2, D, w->fc_w, D, w->fc_b, b.a, F, M, F, D, OV_EPI_BIAS, nullptr, 0, 0, 0, 0, stream));
     // ---- MLP branch: y = x1 + c_proj(gelu(a))
-    OV_TRY(ov_linear_backward(dy, D, nullptr, 0, w->proj_w, F, M, D, F, b.dh, F, nullptr, 0, nullptr, b.lin, b.lin_bytes, stream));      // dh = dy Wproj
-    OV_TRY(ov_gelu_backward(pre, F, b.dh, F, b.dh, F, b.a, F, M, F, cfg->gelu_tanh, stream));                                          // dh -> da (in place), b.a = gelu(a)
-    OV_TRY(ov_linear_backward(dy, D, b.a, F, w->proj_w, F, M, D, F, nullptr, 0, g->proj_w, F, g->proj_b, b.lin, b.lin_bytes, stream));
+    const ov_bf16* act = b.a;
+    if (saved && saved->fc_act && saved->fc_pre) {      // da = (dy Wproj) * gelu'(a) in the product's own epilogue; gelu(a) was kept
+        OV_TRY(linear_backward(dy, D, nullptr, 0, w->proj_w, F, M, D, F, b.dh, F, nullptr, 0, nullptr, b.lin, b.lin_bytes, stream,
+                               cfg->gelu_tanh ? OV_EPI_GELU_GRAD_TANH : OV_EPI_GELU_GRAD_ERF, pre, F));
+        act = saved->fc_act;
+    } else {
+        OV_TRY(ov_linear_backward(dy, D, nullptr, 0, w->proj_w, F, M, D, F, b.dh, F, nullptr, 0, nullptr, b.lin, b.lin_bytes, stream));  // dh = dy Wproj
+        OV_TRY(ov_gelu_backward(pre, F, b.dh, F, b.dh, F, b.a, F, M, F, cfg->gelu_tanh, stream));                                      // dh -> da (in place), b.a = gelu(a)
+    }
+    OV_TRY(ov_linear_backward(dy, D, act, F, w->proj_w, F, M, D, F, nullptr, 0, g->proj_w, F, g->proj_b, b.lin, b.lin_bytes, stream));
     OV_TRY(ov_linear_backward(b.dh, F, b.n2, D, w->fc_w, D, M, F, D, b.t1, D, g->fc_w, D, g->fc_b, b.lin, b.lin_bytes, stream));        // t1 = d ln_2 out
     OV_TRY(ov_layernorm_backward(b.x1, D, w->ln2_w, b.t1, D, dy, D, b.dx1, D, g->ln2_w, g->ln2_b, M, D, eps, b.ln, b.ln_bytes, stream)); // dx1 = dy + ...
     // ---- attention branch: x1 = x + out_proj(attn(qkv))

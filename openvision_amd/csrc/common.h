@@ -149,3 +149,64 @@ __device__ __forceinline__ f32x2_t gelu_tanh_f2(f32x2_t x) {
     const f32x2_t den = f32x2_t{__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])} + 1.0f;
     return x * f32x2_t{__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
 }
+
+// d/dx of the exact-erf GELU, Phi(x) + x phi(x), for the backward's fused epilogue (OV_EPI_GELU_GRAD_ERF), transcendental-free like
+// gelu_erf_f2: gelu'(x) = 0.5 + x_c s(x_c^2), x_c = clamp(x, -4, 4), s = degree-7 Chebyshev-node fit (tools/fit_gelu_grad.py);
+// |error| <= 4.3e-4 everywhere -- the factor multiplies a bf16 gradient whose own rounding is 2^-9 relative.  Two pairs at once,
+// the Horner chains interleaved (see gelu_erf_f2x2).
+__device__ __forceinline__ void gelu_erf_grad_f2x2(f32x2_t& x, f32x2_t& y) {
+    const f32x2_t xc = {__builtin_amdgcn_fmed3f(x[0], -4.0f, 4.0f), __builtin_amdgcn_fmed3f(x[1], -4.0f, 4.0f)};
+    const f32x2_t yc = {__builtin_amdgcn_fmed3f(y[0], -4.0f, 4.0f), __builtin_amdgcn_fmed3f(y[1], -4.0f, 4.0f)};
+    const f32x2_t u = xc * xc, v = yc * yc;
+    f32x2_t q = __builtin_elementwise_fma(u, f32x2_t{-1.933266631e-08f, -1.933266631e-08f}, f32x2_t{1.391892320e-06f, 1.391892320e-06f});
+    f32x2_t r = __builtin_elementwise_fma(v, f32x2_t{-1.933266631e-08f, -1.933266631e-08f}, f32x2_t{1.391892320e-06f, 1.391892320e-06f});
+    q = __builtin_elementwise_fma(q, u, f32x2_t{-4.282898866e-05f, -4.282898866e-05f});
+    r = __builtin_elementwise_fma(r, v, f32x2_t{-4.282898866e-05f, -4.282898866e-05f});
+    q = __builtin_elementwise_fma(q, u, f32x2_t{7.424731401e-04f, 7.424731401e-04f});
+    r = __builtin_elementwise_fma(r, v, f32x2_t{7.424731401e-04f, 7.424731401e-04f});
+    q = __builtin_elementwise_fma(q, u, f32x2_t{-8.057965438e-03f, -8.057965438e-03f});
+    r = __builtin_elementwise_fma(r, v, f32x2_t{-8.057965438e-03f, -8.057965438e-03f});
+    q = __builtin_elementwise_fma(q, u, f32x2_t{5.721020480e-02f, 5.721020480e-02f});
+    r = __builtin_elementwise_fma(r, v, f32x2_t{5.721020480e-02f, 5.721020480e-02f});
+    q = __builtin_elementwise_fma(q, u, f32x2_t{-2.640489873e-01f, -2.640489873e-01f});
+    r = __builtin_elementwise_fma(r, v, f32x2_t{-2.640489873e-01f, -2.640489873e-01f});
+    q = __builtin_elementwise_fma(q, u, f32x2_t{7.976477333e-01f, 7.976477333e-01f});
+    r = __builtin_elementwise_fma(r, v, f32x2_t{7.976477333e-01f, 7.976477333e-01f});
+    x = __builtin_elementwise_fma(xc, q, f32x2_t{0.5f, 0.5f});
+    y = __builtin_elementwise_fma(yc, r, f32x2_t{0.5f, 0.5f});
+}
+// d/dx of the tanh-form GELU: sg + 2 x sg (1 - sg) u'(x), sg = sigmoid(2u), u = sqrt(2/pi) (x + 0.044715 x^3)
+__device__ __forceinline__ f32x2_t gelu_tanh_grad_f2(f32x2_t x) {
+    const f32x2_t x2 = x * x;
+    const f32x2_t u = x * 0.7978845608028654f * __builtin_elementwise_fma(x2, f32x2_t{0.044715f, 0.044715f}, f32x2_t{1.0f, 1.0f});
+    const f32x2_t a = u * -2.8853900817779268f;
+    const f32x2_t den = f32x2_t{__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])} + 1.0f;
+    const f32x2_t sg = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+    const f32x2_t du = __builtin_elementwise_fma(x2, f32x2_t{3.0f * 0.044715f * 0.7978845608028654f, 3.0f * 0.044715f * 0.7978845608028654f},
+                                                 f32x2_t{0.7978845608028654f, 0.7978845608028654f});
+    return __builtin_elementwise_fma(x * 2.0f * sg * (f32x2_t{1.0f, 1.0f} - sg), du, sg);
+}
+
+// The epilogues that read a second operand R (same rows and columns as C): out = combine(bf16(acc + bias), R), per packed bf16 pair.
+//   OV_EPI_BIAS_RESIDUAL (3): o + r        OV_EPI_GELU_GRAD_ERF (4) / _TANH (5): o * gelu'(r)
+template <int EPI>
+__device__ __forceinline__ u32x4_t epi_combine(u32x4_t o, u32x4_t r) {
+    u32x4_t out;
+    if (EPI == 3) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            out[e] = pack_bf16x2(bf16lo_to_f32(o[e]) + bf16lo_to_f32(r[e]), bf16hi_to_f32(o[e]) + bf16hi_to_f32(r[e]));
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) {
+            f32x2_t g0 = {bf16lo_to_f32(r[e]), bf16hi_to_f32(r[e])}, g1 = {bf16lo_to_f32(r[e + 1]), bf16hi_to_f32(r[e + 1])};
+            if (EPI == 4) gelu_erf_grad_f2x2(g0, g1);
+            else { g0 = gelu_tanh_grad_f2(g0); g1 = gelu_tanh_grad_f2(g1); }
+            const f32x2_t v0 = f32x2_t{bf16lo_to_f32(o[e]), bf16hi_to_f32(o[e])} * g0;
+            const f32x2_t v1 = f32x2_t{bf16lo_to_f32(o[e + 1]), bf16hi_to_f32(o[e + 1])} * g1;
+            out[e] = pack_bf16x2(v0[0], v0[1]);
+            out[e + 1] = pack_bf16x2(v1[0], v1[1]);
+        }
+    }
+    return out;
+}

@@ -67,7 +67,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4_t (&acc)[
             bv[j][0] = bv[j][1] = bv[j][2] = bv[j][3] = 0.f;
         }
     }
-    const bool fold = (EPI != OV_EPI_BIAS_RESIDUAL) && g.colsum != nullptr;
+    const bool fold = (EPI < OV_EPI_BIAS_RESIDUAL) && g.colsum != nullptr;
     float sv[4][4];
     if (fold) {
 #pragma unroll
@@ -122,13 +122,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4_t (&acc)[
         u32x4_t v = *(const u32x4_t*)(ep + row * 128 + ((ec ^ (row & 7)) << 4));
         const int64_t m = m0 + wm * 128 + row;
         if (m < g.M && n < g.N) {
-            if (EPI == OV_EPI_BIAS_RESIDUAL) {
+            if (EPI >= OV_EPI_BIAS_RESIDUAL) {
                 const int64_t rrow = g.resid_mod ? (m % g.resid_mod) + g.resid_off : m;
                 const u32x4_t rv = *(const u32x4_t*)(g.R + rrow * g.ldr + n);
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    v[e] = pack_bf16x2(bf16lo_to_f32(v[e]) + bf16lo_to_f32(rv[e]),
-                                       bf16hi_to_f32(v[e]) + bf16hi_to_f32(rv[e]));
+                v = epi_combine<EPI>(v, rv);
             }
             const int64_t orow = g.out_group ? m + m / g.out_group + 1 : m;
             *(u32x4_t*)(g.C + orow * g.ldc + n) = v;
@@ -579,7 +576,7 @@ __device__ __forceinline__ void epilogue_stream(const GemmArgs& g, f32x4_t (&acc
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rv[i][0]) : "v"(src + nc0));
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rv[i][1]) : "v"(src + nc1));
     };
-    if (EPI == OV_EPI_BIAS_RESIDUAL) {
+    if (EPI >= OV_EPI_BIAS_RESIDUAL) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) load_resid(i);
     }
@@ -623,12 +620,7 @@ __device__ __forceinline__ void epilogue_stream(const GemmArgs& g, f32x4_t (&acc
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             u32x4_t o = vo[i][h];
-            if (EPI == OV_EPI_BIAS_RESIDUAL) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    o[e] = pack_bf16x2(bf16lo_to_f32(o[e]) + bf16lo_to_f32(rv[i][h][e]),
-                                       bf16hi_to_f32(o[e]) + bf16hi_to_f32(rv[i][h][e]));
-            }
+            if (EPI >= OV_EPI_BIAS_RESIDUAL) o = epi_combine<EPI>(o, rv[i][h]);
             if (m < (unsigned)g.M && (h ? ncol1 : ncol0)) *(u32x4_t*)(dst + h * 32) = o;
         }
     };
@@ -644,7 +636,7 @@ __device__ __forceinline__ void epilogue_stream(const GemmArgs& g, f32x4_t (&acc
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         if (wm == 1 && g.epi_prio > 0 && i == g.epi_prio) __builtin_amdgcn_s_setprio(0);
-        if (EPI == OV_EPI_BIAS_RESIDUAL && i == 4) {
+        if (EPI >= OV_EPI_BIAS_RESIDUAL && i == 4) {
 #pragma unroll
             for (int k = 4; k < 8; ++k) load_resid(k);
         }
@@ -689,7 +681,7 @@ __device__ __forceinline__ void epilogue_stream(const GemmArgs& g, f32x4_t (&acc
             const u32x2_t s1 = __builtin_amdgcn_permlane16_swap(pk[2 * h][1], pk[2 * h + 1][1], false, false);
             vo[i][h] = u32x4_t{s0[0], s1[0], s0[1], s1[1]};
         }
-        if (EPI == OV_EPI_BIAS_RESIDUAL) {
+        if (EPI >= OV_EPI_BIAS_RESIDUAL) {
             // in flight behind the rows waited for: i == 3 -> after the second batch of loads at i == 4.  Stores start once every
             // load is out: at i == 4 the rows of passes 4-7 (8 loads) are younger than those of passes 0-3; later, per pass, the
             // remaining row loads plus the stores of all earlier passes = 14 every time
@@ -728,7 +720,7 @@ __device__ __forceinline__ void epilogue_stream_lds(const GemmArgs& g, f32x4_t (
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rv[i][it]) : "v"(src));
         }
     };
-    if (EPI == OV_EPI_BIAS_RESIDUAL) {
+    if (EPI >= OV_EPI_BIAS_RESIDUAL) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) load_resid(i);
     }
@@ -768,12 +760,7 @@ __device__ __forceinline__ void epilogue_stream_lds(const GemmArgs& g, f32x4_t (
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             u32x4_t o = vo[i][it];
-            if (EPI == OV_EPI_BIAS_RESIDUAL) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    o[e] = pack_bf16x2(bf16lo_to_f32(o[e]) + bf16lo_to_f32(rv[i][it][e]),
-                                       bf16hi_to_f32(o[e]) + bf16hi_to_f32(rv[i][it][e]));
-            }
+            if (EPI >= OV_EPI_BIAS_RESIDUAL) o = epi_combine<EPI>(o, rv[i][it]);
             const unsigned m = (unsigned)m0 + wm * 128 + i * 16 + it * 8 + er;
             if (!MAPPED) {   // no row map: the lane's row pointer of pass 0, stepped by whole rows
                 if (m < (unsigned)g.M && ncol) *(u32x4_t*)(cbase_lds + (int64_t)(i * 16 + it * 8) * g.ldc) = o;
@@ -797,7 +784,7 @@ __device__ __forceinline__ void epilogue_stream_lds(const GemmArgs& g, f32x4_t (
 #pragma unroll
     for (int i = 0; i <= 8; ++i) {
         if (wm == 1 && g.epi_prio > 0 && i == g.epi_prio) __builtin_amdgcn_s_setprio(0);
-        if (EPI == OV_EPI_BIAS_RESIDUAL && i == 4) {
+        if (EPI >= OV_EPI_BIAS_RESIDUAL && i == 4) {
 #pragma unroll
             for (int k = 4; k < 8; ++k) load_resid(k);
         }
@@ -828,7 +815,7 @@ __device__ __forceinline__ void epilogue_stream_lds(const GemmArgs& g, f32x4_t (
         }
         // rows of pass i-1 (read one pass ago) leave while pass i is in the LDS pipe; with residual rows the first
         // four passes are held back until the second half of the residual loads is out
-        if (EPI == OV_EPI_BIAS_RESIDUAL) {
+        if (EPI >= OV_EPI_BIAS_RESIDUAL) {
             // in flight behind the rows waited for: i == 4: rows of passes 4-7 (8 loads); later: the remaining row loads
             // plus the stores of all earlier passes = 14 every time
             if (i == 4) { wait_resid(0, 4, 8); put(0); put(1); put(2); put(3); }
@@ -1204,7 +1191,7 @@ int launch(GemmArgs a, hipStream_t st) {
         // needs more than the 256 VGPRs a wave has here and spills, which the hand-counted waits cannot tolerate).  Bias-only
         // epilogue (QKV, projections): LDS-transposed coalesced stores measure faster in the model (9.5-9.8 against 10.0-10.3 ms per
         // step for the QKV GEMMs); OVHIP_GEMM_EPI_DIRECT=1 selects the direct form there too.
-        constexpr bool CAN_FOLD = EPI != OV_EPI_BIAS_RESIDUAL;
+        constexpr bool CAN_FOLD = EPI < OV_EPI_BIAS_RESIDUAL;
         const bool mapped = a.out_group != 0 || a.resid_mod != 0;          // row maps: the patch embedding's GEMM only
         if (EPI == OV_EPI_BIAS) {
             static int direct0 = -1;
@@ -1244,9 +1231,10 @@ extern "C" int ov_gemm(const ov_bf16* A, int64_t lda, const ov_bf16* W, int64_t 
     if (lda < K || ldw < K || ldc < N) return OV_ERR_INVALID;
     if (((uintptr_t)A | (uintptr_t)W | (uintptr_t)C) & 15) return OV_ERR_INVALID;
     if (bias && ((uintptr_t)bias & 15)) return OV_ERR_INVALID;
-    if (epilogue == OV_EPI_BIAS_RESIDUAL) {
+    if (epilogue >= OV_EPI_BIAS_RESIDUAL) {
         if (!R || ldr % 8 || ldr < N || ((uintptr_t)R & 15)) return OV_ERR_INVALID;
     }
+    if (epilogue > OV_EPI_BIAS_RESIDUAL && (out_group || resid_mod)) return OV_ERR_UNSUPPORTED;      // row maps: bias / residual only
     if (out_group < 0 || resid_mod < 0 || resid_off < 0) return OV_ERR_INVALID;
     const int64_t tiles_m = (M + BM - 1) / BM;
     const int64_t tiles_n = (N + BN - 1) / BN;
@@ -1260,6 +1248,8 @@ extern "C" int ov_gemm(const ov_bf16* A, int64_t lda, const ov_bf16* W, int64_t 
         case OV_EPI_BIAS_GELU_ERF: return launch<OV_EPI_BIAS_GELU_ERF>(a, st);
         case OV_EPI_BIAS_GELU_TANH: return launch<OV_EPI_BIAS_GELU_TANH>(a, st);
         case OV_EPI_BIAS_RESIDUAL: return launch<OV_EPI_BIAS_RESIDUAL>(a, st);
+        case OV_EPI_GELU_GRAD_ERF: return launch<OV_EPI_GELU_GRAD_ERF>(a, st);
+        case OV_EPI_GELU_GRAD_TANH: return launch<OV_EPI_GELU_GRAD_TANH>(a, st);
         default: return OV_ERR_INVALID;
     }
 }
@@ -1335,7 +1325,7 @@ extern "C" int ov_gemm_ln(const ov_bf16* X, int64_t ldx, const ov_bf16* Wg, int6
                           const float* rowstats, ov_bf16* C, int64_t ldc, int64_t M, int N, int K, int epilogue,
                           ov_stream_t stream) {
     if (!colsum || !rowstats || !cvec) return OV_ERR_INVALID;
-    if (epilogue == OV_EPI_BIAS_RESIDUAL) return OV_ERR_UNSUPPORTED;
+    if (epilogue >= OV_EPI_BIAS_RESIDUAL) return OV_ERR_UNSUPPORTED;
     if ((((uintptr_t)colsum | (uintptr_t)cvec) & 15) || ((uintptr_t)rowstats & 7)) return OV_ERR_INVALID;
     g_colsum = colsum;
     g_rowstats = rowstats;

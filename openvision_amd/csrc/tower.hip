@@ -451,9 +451,9 @@ extern "C" int ov_block_backward(const ov_tower_cfg* cfg, const ov_block_weights
                                  size_t workspace_bytes, ov_stream_t stream);
 extern "C" size_t ov_block_backward_workspace_bytes(const ov_tower_cfg* cfg, int B, int L);
 
-// saved activations of one layer: [x | qkv | attention out | x1 | ln_1 out | ln_2 out | c_fc pre-activation], 8 D + mlp_pad bf16 per
-// token (288 GB of HBM: keep, do not recompute)
-static inline size_t saved_per_token(const ov_tower_cfg& c) { return (size_t)8 * c.width + c.mlp_pad; }
+// saved activations of one layer: [x | qkv | attention out | x1 | ln_1 out | ln_2 out | c_fc pre-activation | c_fc activation],
+// 8 D + 2 mlp_pad bf16 per token (288 GB of HBM: keep, do not recompute)
+static inline size_t saved_per_token(const ov_tower_cfg& c) { return (size_t)8 * c.width + 2 * (size_t)c.mlp_pad; }
 extern "C" size_t ov_tower_saved_bytes(const ov_tower* t, int B, int L) {
     if (!t || B <= 0 || L <= 0) return 0;
     return (size_t)t->cfg.layers * B * L * saved_per_token(t->cfg) * sizeof(ov_bf16);
@@ -468,9 +468,7 @@ extern "C" int ov_tower_forward_saving(const ov_tower* t, ov_bf16* x, ov_bf16* s
     const ov_tower_cfg& c = t->cfg;
     const int D = c.width, H = c.heads, hd = D / H;
     const int64_t M = (int64_t)B * L;
-    const int ldb = 3 * D > c.mlp_pad ? 3 * D : c.mlp_pad;
-    ov_bf16* big = (ov_bf16*)((char*)workspace + align_up((size_t)M * D * 2, 256));      // same plan as ov_tower_forward
-    const float scale = 1.0f / sqrtf((float)hd);
+    const float scale = 1.0f / sqrtf((float)hd);              // (every intermediate lands in `saved`: the workspace stays unused)
     const int gelu = c.gelu_tanh ? OV_EPI_BIAS_GELU_TANH : OV_EPI_BIAS_GELU_ERF;
     const size_t spt = saved_per_token(c);
     for (int i = 0; i < c.layers; ++i)
@@ -488,6 +486,7 @@ extern "C" int ov_tower_forward_saving(const ov_tower* t, ov_bf16* x, ov_bf16* s
         ov_bf16* sn1 = sx1 + (size_t)M * D;
         ov_bf16* sn2 = sn1 + (size_t)M * D;
         ov_bf16* spre = sn2 + (size_t)M * D;
+        ov_bf16* sact = spre + (size_t)M * c.mlp_pad;
         ov_bf16* y = i + 1 < c.layers ? saved + (size_t)(i + 1) * M * spt : x;
         int rc;
         // the same operator sequence as run_block, with qkv / attention output / x1 written where the backward will read them
@@ -496,8 +495,8 @@ extern "C" int ov_tower_forward_saving(const ov_tower* t, ov_bf16* x, ov_bf16* s
         if ((rc = ov_attention(sqkv, 3 * D, so, D, B, L, H, hd, scale, stream))) return rc;
         if ((rc = ov_gemm(so, D, w.out_w, D, w.out_b, sx1, D, M, D, D, OV_EPI_BIAS_RESIDUAL, sx, D, 0, 0, 0, stream))) return rc;
         if ((rc = ov_layernorm(sx1, OV_BF16, D, w.ln2_w, w.ln2_b, sn2, OV_BF16, D, M, D, c.ln_eps, stream))) return rc;
-        if ((rc = ov_gemm_keep(sn2, D, w.fc_w, D, w.fc_b, big, ldb, spre, c.mlp_pad, M, c.mlp_pad, D, gelu, stream))) return rc;
-        if ((rc = ov_gemm(big, ldb, w.proj_w, c.mlp_pad, w.proj_b, y, D, M, D, c.mlp_pad, OV_EPI_BIAS_RESIDUAL, sx1, D, 0, 0, 0, stream)))
+        if ((rc = ov_gemm_keep(sn2, D, w.fc_w, D, w.fc_b, sact, c.mlp_pad, spre, c.mlp_pad, M, c.mlp_pad, D, gelu, stream))) return rc;
+        if ((rc = ov_gemm(sact, c.mlp_pad, w.proj_w, c.mlp_pad, w.proj_b, y, D, M, D, c.mlp_pad, OV_EPI_BIAS_RESIDUAL, sx1, D, 0, 0, 0, stream)))
             return rc;
     }
     return OV_OK;
@@ -525,6 +524,7 @@ extern "C" int ov_tower_backward(const ov_tower* t, const ov_bf16* saved, ov_bf1
         sv.ln1_out = sv.x1 + (size_t)M * D;
         sv.ln2_out = sv.ln1_out + (size_t)M * D;
         sv.fc_pre = sv.ln2_out + (size_t)M * D;
+        sv.fc_act = sv.fc_pre + (size_t)M * c.mlp_pad;
         const int rc = ov_block_backward(&c, &t->blocks[i], sx, &sv, dx, dx, &grads[i], B, L, workspace, workspace_bytes, stream);
         if (rc) return rc;
     }

@@ -71,6 +71,26 @@ def test_gemm_keep_pre_activation_is_the_bias_gemm_and_output_the_gelu_gemm(M, N
     assert not out[:, N:].any() and not pre[:, N:].any()
 
 
+@pytest.mark.parametrize("M,N,K,tanh", [(333, 768, 192, False), (257 * 70 + 9, 4096, 1024, False), (4100, 4304, 1152, True),
+                                        (65792, 1024, 256, False), (300, 512, 2048, True)])
+def test_gemm_gelu_grad_epilogue(M, N, K, tanh):
+    """OV_EPI_GELU_GRAD_ERF / _TANH: C = bf16(bf16(A W^T) * gelu'(R)) -- the backward through the MLP's GELU folded into dy Wproj.
+    Against fp64 gelu' from autograd; the polynomial erf form is within 4.3e-4 of the exact derivative, and both kernels (small and
+    persistent grids) must agree with the two-step route (plain product, then ov_gelu_backward) to that bound + one bf16 rounding."""
+    a, w = rnd(M, K, seed=40).to(torch.bfloat16).to(DEV), (rnd(N, K, seed=41) / K ** 0.5).to(torch.bfloat16).to(DEV)
+    pre = (rnd(M, N, seed=42) * 1.5).to(torch.bfloat16).to(DEV)
+    got = H.gemm(a, w, None, epi=5 if tanh else 4, resid=pre).float()
+    dh = H.gemm(a, w, None, epi=0).double()
+    x = pre.double().requires_grad_(True)
+    torch.nn.functional.gelu(x, approximate="tanh" if tanh else "none").sum().backward()
+    want = dh * x.grad
+    err = (got.double() - want).abs()
+    bound = dh.abs() * (6e-4 + 1.13 * 2 ** -8) + 1e-6               # polynomial + one bf16 rounding of a product <= 1.13 |dh|
+    assert bool((err <= bound).all()), float((err - bound).max())
+    two_step = H.gelu_backward(pre, H.gemm(a, w, None, epi=0), tanh).float()
+    assert (got - two_step).abs().max().item() <= float((dh.abs() * (6e-4 + 1.13 * 2 ** -7)).max())
+
+
 @pytest.mark.parametrize("M,N,K,epi", [(771, 3072, 1024, 0), (300, 768, 192, 1), (65535, 1024, 1024, 0), (200, 2304, 768, 2)])
 def test_gemm_ln_fold_matches_layernorm_then_linear(M, N, K, epi):
     """ov_rowstats + ov_gemm_ln == Linear(LayerNorm(x)) (transformer.py:263-264) without materialising LN(x)."""
