@@ -11,9 +11,9 @@ Opt-in: the inference entry points of ``openvision_amd.model`` never build a gra
     loss = ClipLoss(...)(img_f, txt_f, scale)                               # openvision_amd.loss.ClipLoss
     loss.backward()                                                         # .grad on every parameter, as with the reference
 
-Activation memory: the tower keeps, per layer and token, the block input, the packed qkv, the attention output and the mid-block
-residual (6 D bf16: 19 GB for L/14 at B=256, sized for the 288 GB of an MI355X); the LayerNorm outputs and the c_fc
-pre-activation are recomputed during the backward.  Every preset is covered: head dims 72 / 80 (So400m, H/14) take the streaming
+Activation memory: the tower keeps, per layer and token, the block input, the packed qkv, the attention output, the mid-block
+residual, both LayerNorm outputs and the c_fc pre-activation and activation (8 D + 2 mlp bf16: 52 GB for L/14 at B=256, sized for
+the 288 GB of an MI355X); the backward runs nothing of the forward again.  Every preset is covered: head dims 72 / 80 (So400m, H/14) take the streaming
 attention backward with d zero-padded to 96, an MLP width that is not a multiple of 64 (So400m) is zero-padded.
 """
 from __future__ import annotations
