@@ -126,6 +126,10 @@ int ov_rowstats(const ov_bf16* x, int64_t ldx, float* rowstats, int64_t rows, in
  * hd == 64 takes the tuned kernels; any other multiple of 8 up to 96 (So400m: 72, H/14: 80) a generic one. */
 int ov_attention(const ov_bf16* qkv, int64_t ld_qkv, ov_bf16* out, int64_t ld_out,
                  int B, int L, int H, int hd, float scale, ov_stream_t stream);
+/* ov_attention that also keeps lse[B*H][Lp] (Lp = L rounded up to 32, fp32): the log-sum-exp of every query row's scaled scores in
+ * log2 units, for ov_attention_backward_saved.  head_dim 64 and L <= 288 only (OV_ERR_UNSUPPORTED otherwise). */
+int ov_attention_lse(const ov_bf16* qkv, int64_t ld_qkv, ov_bf16* out, int64_t ld_out, float* lse, int B, int L, int H, int hd, float scale,
+                     ov_stream_t stream);
 
 /* Patch gather for conv1: image [B,3,S,S] (img_dtype) -> P[B*g*g, Kpad] bf16,
  * column index c*P*P + i*P + j (the flattening of conv1.weight[D,3,P,P]); columns >= 3*P*P zeroed. */
@@ -278,6 +282,11 @@ size_t ov_attention_backward_workspace_bytes(int B, int L, int H, int hd);
 int ov_attention_backward(const ov_bf16* qkv, int64_t ld_qkv, const ov_bf16* out, int64_t ld_out, const ov_bf16* dout, int64_t ld_dout,
                           ov_bf16* dqkv, int64_t ld_dqkv, int B, int L, int H, int hd, float scale, void* workspace,
                           size_t workspace_bytes, ov_stream_t stream);
+/* The same with the forward's row statistics kept by ov_attention_lse (lse [B*H][L rounded up to 32] fp32, or NULL): the resident
+ * kernel (head_dim 64, L <= 288) then skips its own score pass; the streaming kernels ignore it. */
+int ov_attention_backward_saved(const ov_bf16* qkv, int64_t ld_qkv, const ov_bf16* out, int64_t ld_out, const ov_bf16* dout, int64_t ld_dout,
+                                ov_bf16* dqkv, int64_t ld_dqkv, const float* lse, int B, int L, int H, int hd, float scale, void* workspace,
+                                size_t workspace_bytes, ov_stream_t stream);
 
 /* da = dh * gelu'(a) on the pre-activation a [rows, N] (tanh_form = 0: exact erf GELU, vision; 1: tanh form, text).  N % 8 == 0.
  * h_out (optional) receives gelu(a).  da may alias dh and h_out may alias a (element-wise, in place). */
@@ -392,6 +401,7 @@ typedef struct {      /* optional forward intermediates kept for the backward (t
     const ov_bf16* ln2_out;    /* [B*L, D]   ln_2(x1), or NULL = recomputed */
     const ov_bf16* fc_act;     /* [B*L, mlp_pad]  gelu(fc_pre), or NULL = recomputed; with fc_pre set too, the backward folds the GELU
                                 * derivative into the epilogue of dy Wproj (OV_EPI_GELU_GRAD_*) and runs no element-wise pass */
+    const float* attn_lse;     /* [B*heads][L rounded up to 32]  row log-sum-exp from ov_attention_lse, or NULL = recomputed */
 } ov_block_saved;
 size_t ov_block_backward_workspace_bytes(const ov_tower_cfg* cfg, int B, int L);
 int ov_block_backward(const ov_tower_cfg* cfg, const ov_block_weights* w, const ov_bf16* x, const ov_block_saved* saved /* or NULL */,
@@ -399,8 +409,8 @@ int ov_block_backward(const ov_tower_cfg* cfg, const ov_block_weights* w, const 
                       ov_stream_t stream);
 
 /* Training-side tower entry points.  ov_tower_forward_saving = the tower forward on the caller's stream that keeps, per layer and
- * token, [x | qkv | attention out | x1 | ln_1 out | ln_2 out | c_fc pre-activation | c_fc activation] (8 D + 2 mlp_pad bf16; `saved`
- * holds ov_tower_saved_bytes: 52 GB for L/14 at batch 256 — sized for the 288 GB of an MI355X: nothing of the forward is run a second time
+ * token, [x | qkv | attention out | x1 | ln_1 out | ln_2 out | c_fc pre-activation | c_fc activation] (8 D + 2 mlp_pad bf16, plus the
+ * attention's fp32 row log-sum-exp per layer; `saved` holds ov_tower_saved_bytes: 52 GB for L/14 at batch 256 — sized for the 288 GB of an MI355X: nothing of the forward is run a second time
  * by the backward).  bf16 path; the blocks must hold
  * the module's own, unfolded weights.  ov_tower_backward runs ov_block_backward over the layers in reverse: dx [B*L, D] holds
  * d loss / d (tower output) on entry and d loss / d (tower input) on return; grads[layer] receives that block's parameter gradients

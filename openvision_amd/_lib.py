@@ -34,7 +34,7 @@ class BlockGrads(C.Structure):
 
 
 class BlockSaved(C.Structure):
-    _fields_ = [(n, c_void_p) for n in ("qkv", "attn_out", "x1", "fc_pre", "ln1_out", "ln2_out", "fc_act")]
+    _fields_ = [(n, c_void_p) for n in ("qkv", "attn_out", "x1", "fc_pre", "ln1_out", "ln2_out", "fc_act", "attn_lse")]
 
 
 class BlockFp8(C.Structure):
@@ -100,6 +100,9 @@ SIGNATURES = {
                                 c_int, c_void_p]),
     "ov_gemm_tn_batched": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int64, c_int,
                                    c_void_p, c_void_p]),
+    "ov_attention_lse": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "ov_attention_backward_saved": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int, c_int,
+                                            c_int, c_float, c_void_p, c_size_t, c_void_p]),
     "ov_attention_backward_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "ov_attention_backward": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int,
                                       c_float, c_void_p, c_size_t, c_void_p]),

@@ -233,6 +233,7 @@ struct AttnPArgs {
     const float* out_amax;        // OUT8: the output is e4m3 bytes (ldo in bytes) with the static scale 2 * (*out_amax) / 448
     float* amax_next;             // OUT8, optional: running maximum of |output| (the next call's scale)
     int lone_valu;                // 1: a single-key last tile is folded in on the VALU (OVHIP_ATTN_LONEKEY=0 keeps the tile step)
+    float* lse;                   // optional (training forward, bf16 output): lse[head][KC] = row log-sum-exp of scale * q.k in log2 units
 };
 
 __device__ __forceinline__ void stage_head(const AttnPArgs& a, int bh, char* slot, int wave, int lane, int nthreads) {
@@ -631,8 +632,19 @@ __global__ __launch_bounds__(DEEP ? 512 : 640, DEEP ? 2 : 3) void attn_fwd_hd64_
 #undef OV_ST16
         }
         // everything but this head's stores (8 dword stores with e4m3 output, 4 dwordx4 stores otherwise) has completed
-        if (OUT8) asm volatile("s_waitcnt vmcnt(8)" : "+v"(qn[0]), "+v"(qn[1]), "+v"(qn[2]), "+v"(qn[3]) :: "memory");
-        else asm volatile("s_waitcnt vmcnt(4)" : "+v"(qn[0]), "+v"(qn[1]), "+v"(qn[2]), "+v"(qn[3]) :: "memory");
+        if (OUT8) {
+            asm volatile("s_waitcnt vmcnt(8)" : "+v"(qn[0]), "+v"(qn[1]), "+v"(qn[2]), "+v"(qn[3]) :: "memory");
+        } else if (a.lse != nullptr) {
+            // kept for the backward (ov_attention_backward_saved): m and l are the same in both half-waves, rows past L repeat row
+            // L - 1 (clamped Q row): duplicate stores of one value.  One more store behind the four of the output.
+            const float v = m + __builtin_amdgcn_logf(l);                                                      // v_log_f32 = log2
+            const float* lb = a.lse + (int64_t)bh * KC;                                                         // uniform
+            const unsigned loff = row_offset(1, 0, 4u);
+            asm volatile("global_store_dword %0, %1, %2" :: "v"(loff), "v"(v), "s"(lb) : "memory");
+            asm volatile("s_waitcnt vmcnt(5)" : "+v"(qn[0]), "+v"(qn[1]), "+v"(qn[2]), "+v"(qn[3]) :: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(4)" : "+v"(qn[0]), "+v"(qn[1]), "+v"(qn[2]), "+v"(qn[3]) :: "memory");
+        }
     }
 }
 
@@ -989,12 +1001,21 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_generic(const AttnArgs a, int
 
 namespace {
 int attention_impl(const ov_bf16* qkv, int64_t ld_qkv, ov_bf16* out, int64_t ld_out, int B, int L, int H, int hd, float scale,
-                   const float* out_amax, float* amax_next, ov_stream_t stream);
+                   const float* out_amax, float* amax_next, float* lse, ov_stream_t stream);
 }
 
 extern "C" int ov_attention(const ov_bf16* qkv, int64_t ld_qkv, ov_bf16* out, int64_t ld_out, int B, int L,
                             int H, int hd, float scale, ov_stream_t stream) {
-    return attention_impl(qkv, ld_qkv, out, ld_out, B, L, H, hd, scale, nullptr, nullptr, stream);
+    return attention_impl(qkv, ld_qkv, out, ld_out, B, L, H, hd, scale, nullptr, nullptr, nullptr, stream);
+}
+
+// ov_attention that also keeps the softmax statistics for ov_attention_backward_saved: lse[B*H][Lp] (Lp = L rounded up to 32) = the
+// log-sum-exp of every query row's scaled scores, in log2 units (m + log2 l of the online softmax).  Only for the shapes the resident
+// backward kernel takes (head_dim 64, L <= 288); OV_ERR_UNSUPPORTED otherwise -- call ov_attention and let the backward recompute.
+extern "C" int ov_attention_lse(const ov_bf16* qkv, int64_t ld_qkv, ov_bf16* out, int64_t ld_out, float* lse, int B, int L, int H, int hd,
+                                float scale, ov_stream_t stream) {
+    if (!lse || ((uintptr_t)lse & 3)) return OV_ERR_INVALID;
+    return attention_impl(qkv, ld_qkv, out, ld_out, B, L, H, hd, scale, nullptr, nullptr, lse, stream);
 }
 
 // Same attention, output written as e4m3 bytes out8[B*L, H*64] (ld_out in bytes) with the static scale 2 * (*out_amax) / 448
@@ -1003,17 +1024,18 @@ extern "C" int ov_attention_fp8out(const ov_bf16* qkv, int64_t ld_qkv, unsigned 
                                    int hd, float scale, const float* out_amax, float* out_amax_next, ov_stream_t stream) {
     if (!out_amax) return OV_ERR_INVALID;
     if (hd != 64) return OV_ERR_UNSUPPORTED;
-    return attention_impl(qkv, ld_qkv, (ov_bf16*)out8, ld_out, B, L, H, hd, scale, out_amax, out_amax_next, stream);
+    return attention_impl(qkv, ld_qkv, (ov_bf16*)out8, ld_out, B, L, H, hd, scale, out_amax, out_amax_next, nullptr, stream);
 }
 
 namespace {
 int attention_impl(const ov_bf16* qkv, int64_t ld_qkv, ov_bf16* out, int64_t ld_out, int B, int L, int H, int hd, float scale,
-                   const float* out_amax, float* amax_next, ov_stream_t stream) {
+                   const float* out_amax, float* amax_next, float* lse, ov_stream_t stream) {
     if (!qkv || !out || B <= 0 || L <= 0 || H <= 0) return OV_ERR_INVALID;
     if (hd <= 0 || hd % 8 || hd > 96) return OV_ERR_UNSUPPORTED;
     if (ld_qkv % 8 || ld_out % 8 || ld_qkv < 3 * H * hd || ld_out < H * hd) return OV_ERR_INVALID;
     if (((uintptr_t)qkv | (uintptr_t)out) & 15) return OV_ERR_INVALID;
     const bool out8 = out_amax != nullptr;
+    if (lse != nullptr && (hd != 64 || (L + 31) / 32 * 32 > 288 || out8)) return OV_ERR_UNSUPPORTED;   // the resident backward's shapes only
     if (hd != 64) {                                      // So400m (72) / H (80): generic padded-head kernel
         AttnArgs g;
         g.qkv = qkv; g.ldq = ld_qkv; g.out = out; g.ldo = ld_out;
@@ -1048,7 +1070,7 @@ int attention_impl(const ov_bf16* qkv, int64_t ld_qkv, ov_bf16* out, int64_t ld_
     if (lp <= 320 && !force_v1 && (int64_t)L * ld_qkv * 2 < 0x7fffffffLL && (int64_t)L * ld_out * 2 < 0x7fffffffLL) {
         AttnPArgs p;
         p.qkv = qkv; p.ldq = ld_qkv; p.out = out; p.ldo = ld_out;
-        p.L = L; p.H = H; p.nqt = a.nqt; p.KC = lp; p.nheads = B * H; p.scale_log2 = a.scale_log2; p.out_amax = out_amax; p.amax_next = amax_next;
+        p.L = L; p.H = H; p.nqt = a.nqt; p.KC = lp; p.nheads = B * H; p.scale_log2 = a.scale_log2; p.out_amax = out_amax; p.amax_next = amax_next; p.lse = lse;
         { static int lk = -1; if (lk < 0) { const char* e = getenv("OVHIP_ATTN_LONEKEY"); lk = (e && e[0] == '0') ? 0 : 1; } p.lone_valu = lk; }
         static OvPerDeviceOnce attr2;
         const int dev_attr2 = ov_current_device();
@@ -1083,6 +1105,7 @@ int attention_impl(const ov_bf16* qkv, int64_t ld_qkv, ov_bf16* out, int64_t ld_
         OV_LAUNCH_CHECK();
         return OV_OK;
     }
+    if (lse != nullptr) return OV_ERR_UNSUPPORTED;       // (OVHIP_ATTN_V1 / row pitches beyond 2 GiB: no kept lse)
     if (lp > 320 && !force_v1) {
         AttnSArgs sa;
         sa.qkv = qkv; sa.ldq = ld_qkv; sa.out = out; sa.ldo = ld_out;

@@ -25,6 +25,7 @@ struct AttnBwdArgs {
     ov_bf16* dqkv; int64_t lddq;              // [B*L, 3*H*64]  (dq | dk | dv)
     int L, H, KC;
     float scale, scale_log2;
+    const float* lse_in;                      // optional: [B*H][KC] row lse kept by the forward (ov_attention_lse): pass 1 is skipped
 };
 
 __device__ __forceinline__ bf16x8_t join8(u32x2_t a, u32x2_t b) {
@@ -55,6 +56,7 @@ __device__ __forceinline__ bf16x8_t pack8(const f32x16_t& t, int s) {
 }
 __device__ __forceinline__ float swap_halves(float v) { return __shfl_xor(v, 32, 64); }
 
+template <bool SAVED>
 __global__ __launch_bounds__(640) void attn_bwd_hd64(const AttnBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -114,8 +116,9 @@ __global__ __launch_bounds__(640) void attn_bwd_hd64(const AttnBwdArgs a) {
 #pragma unroll
         for (int st = 0; st < 4; ++st) { qB[st] = frag(qimg, i, st); dB[st] = frag(dimg, i, st); }
         // pass 1: lse (log2 units) of row `query`; a lane sees the keys (t&3) + 8 (t>>2) + 4 h2 of each tile
+        // (SAVED: the forward kept it -- no score pass, no exponentials here)
         float m = -INFINITY, l = 0.f;
-        for (int j = 0; j < nt; ++j) {
+        for (int j = 0; j < (SAVED ? 0 : nt); ++j) {
             f32x16_t s;
 #pragma unroll
             for (int t = 0; t < 16; ++t) s[t] = 0.f;
@@ -137,13 +140,16 @@ __global__ __launch_bounds__(640) void attn_bwd_hd64(const AttnBwdArgs a) {
                 m = mn;
             }
         }
-        {
+        float lse2;
+        if (SAVED) {
+            lse2 = a.lse_in[(int64_t)blockIdx.x * KC + query];   // rows past L hold row L - 1's value (never used: p = 0 there)
+        } else {
             const float mo = swap_halves(m), lo = swap_halves(l);
             const float mn = fmaxf(m, mo);                       // finite: key 0 is always valid for one of the halves
             l = l * (m > -INFINITY ? __builtin_amdgcn_exp2f(m - mn) : 0.f) + lo * (mo > -INFINITY ? __builtin_amdgcn_exp2f(mo - mn) : 0.f);
             m = mn;
+            lse2 = m + __builtin_amdgcn_logf(l);                 // v_log_f32 = log2
         }
-        const float lse2 = m + __builtin_amdgcn_logf(l);         // v_log_f32 = log2
         // delta = sum_d dO[q, d] O[q, d]: this lane takes d half h2
         float delta = 0.f;
         {
@@ -552,9 +558,11 @@ int launch_stream(const AttnBwdSArgs& g, int B, hipStream_t st) {
 }
 }  // namespace
 
-extern "C" int ov_attention_backward(const ov_bf16* qkv, int64_t ld_qkv, const ov_bf16* out, int64_t ld_out, const ov_bf16* dout,
-                                     int64_t ld_dout, ov_bf16* dqkv, int64_t ld_dqkv, int B, int L, int H, int hd, float scale,
-                                     void* workspace, size_t workspace_bytes, ov_stream_t stream) {
+// lse (or NULL): the forward's row statistics from ov_attention_lse, [B*H][L rounded up to 32]; used by the resident kernel
+// (head_dim 64, L <= 288), ignored by the streaming kernels
+extern "C" int ov_attention_backward_saved(const ov_bf16* qkv, int64_t ld_qkv, const ov_bf16* out, int64_t ld_out, const ov_bf16* dout,
+                                           int64_t ld_dout, ov_bf16* dqkv, int64_t ld_dqkv, const float* lse, int B, int L, int H, int hd,
+                                           float scale, void* workspace, size_t workspace_bytes, ov_stream_t stream) {
     if (!qkv || !out || !dout || !dqkv || B <= 0 || L <= 0 || H <= 0) return OV_ERR_INVALID;
     if (hd <= 0 || hd % 8 || hd > 96) return OV_ERR_UNSUPPORTED;
     if (ld_qkv % 8 || ld_out % 8 || ld_dout % 8 || ld_dqkv % 8 || ld_qkv < 3 * H * hd || ld_dqkv < 3 * H * hd || ld_out < H * hd ||
@@ -566,16 +574,20 @@ extern "C" int ov_attention_backward(const ov_bf16* qkv, int64_t ld_qkv, const o
     a.qkv = qkv; a.ldq = ld_qkv; a.out = out; a.ldo = ld_out; a.dout = dout; a.lddo = ld_dout; a.dqkv = dqkv; a.lddq = ld_dqkv;
     a.L = L; a.H = H; a.KC = (L + 31) / 32 * 32;
     a.scale = scale; a.scale_log2 = scale * 1.4426950408889634f;
+    a.lse_in = lse;
     if (hd == 64 && L <= 288) {                                 // Q, K, V, dO of a head resident in LDS
         static OvPerDeviceOnce attr;
         const int dev = ov_current_device();
         if (attr.need(dev)) {
-            hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_hd64, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_hd64<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)attn_bwd_hd64<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return ov_hip(e);
             attr.mark(dev);
         }
         const size_t smem = (size_t)4 * a.KC * 128 + (size_t)2 * a.KC * sizeof(float);
-        hipLaunchKernelGGL(attn_bwd_hd64, dim3((unsigned)(B * H)), dim3((unsigned)(a.KC / 32 * 64)), smem, (hipStream_t)stream, a);
+        const dim3 grid((unsigned)(B * H)), blk((unsigned)(a.KC / 32 * 64));
+        if (lse != nullptr) hipLaunchKernelGGL(attn_bwd_hd64<true>, grid, blk, smem, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL(attn_bwd_hd64<false>, grid, blk, smem, (hipStream_t)stream, a);
         OV_LAUNCH_CHECK();
         return OV_OK;
     }
@@ -590,4 +602,11 @@ extern "C" int ov_attention_backward(const ov_bf16* qkv, int64_t ld_qkv, const o
     g.dlt = g.lse + (size_t)B * H * g.Lpad;
     if ((int64_t)B * H * g.nblk > 0x7fffffffLL) return OV_ERR_UNSUPPORTED;
     return hd <= 64 ? launch_stream<2>(g, B, (hipStream_t)stream) : launch_stream<3>(g, B, (hipStream_t)stream);
+}
+
+extern "C" int ov_attention_backward(const ov_bf16* qkv, int64_t ld_qkv, const ov_bf16* out, int64_t ld_out, const ov_bf16* dout,
+                                     int64_t ld_dout, ov_bf16* dqkv, int64_t ld_dqkv, int B, int L, int H, int hd, float scale,
+                                     void* workspace, size_t workspace_bytes, ov_stream_t stream) {
+    return ov_attention_backward_saved(qkv, ld_qkv, out, ld_out, dout, ld_dout, dqkv, ld_dqkv, nullptr, B, L, H, hd, scale, workspace,
+                                       workspace_bytes, stream);
 }

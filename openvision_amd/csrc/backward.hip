@@ -20,6 +20,9 @@ extern "C" int ov_attention(const ov_bf16* qkv, int64_t ld_qkv, ov_bf16* out, in
 extern "C" int ov_attention_backward(const ov_bf16* qkv, int64_t ld_qkv, const ov_bf16* out, int64_t ld_out, const ov_bf16* dout,
                                      int64_t ld_dout, ov_bf16* dqkv, int64_t ld_dqkv, int B, int L, int H, int hd, float scale,
                                      void* workspace, size_t workspace_bytes, ov_stream_t stream);
+extern "C" int ov_attention_backward_saved(const ov_bf16* qkv, int64_t ld_qkv, const ov_bf16* out, int64_t ld_out, const ov_bf16* dout,
+                                           int64_t ld_dout, ov_bf16* dqkv, int64_t ld_dqkv, const float* lse, int B, int L, int H, int hd,
+                                           float scale, void* workspace, size_t workspace_bytes, ov_stream_t stream);
 extern "C" size_t ov_attention_backward_workspace_bytes(int B, int L, int H, int hd);
 extern "C" int ov_gemm_batched(const ov_bf16* A, int64_t lda, int64_t stride_a, const ov_bf16* W, int64_t ldw, int64_t stride_w,
                                ov_bf16* C, int64_t ldc, int64_t stride_c, int64_t M, int N, int K, int batch, ov_stream_t stream);
@@ -598,7 +601,8 @@ extern "C" int ov_block_backward(const ov_tower_cfg* cfg, const ov_block_weights
     OV_TRY(ov_layernorm_backward(b.x1, D, w->ln2_w, b.t1, D, dy, D, b.dx1, D, g->ln2_w, g->ln2_b, M, D, eps, b.ln, b.ln_bytes, stream)); // dx1 = dy + ...
     // ---- attention branch: x1 = x + out_proj(attn(qkv))
     OV_TRY(ov_linear_backward(b.dx1, D, b.o, D, w->out_w, D, M, D, D, b.t1, D, g->out_w, D, g->out_b, b.lin, b.lin_bytes, stream));     // t1 = d attention out
-    OV_TRY(ov_attention_backward(b.qkv, 3 * D, b.o, D, b.t1, D, b.dqkv, 3 * D, B, L, H, hd, scale, b.att, b.att_bytes, stream));
+    OV_TRY(ov_attention_backward_saved(b.qkv, 3 * D, b.o, D, b.t1, D, b.dqkv, 3 * D, saved ? saved->attn_lse : nullptr, B, L, H, hd, scale, b.att,
+                                       b.att_bytes, stream));
     OV_TRY(ov_linear_backward(b.dqkv, 3 * D, b.n1, D, w->qkv_w, D, M, 3 * D, D, b.t1, D, g->qkv_w, D, g->qkv_b, b.lin, b.lin_bytes, stream));  // t1 = d ln_1 out
     OV_TRY(ov_layernorm_backward(x, D, w->ln1_w, b.t1, D, b.dx1, D, dx, D, g->ln1_w, g->ln1_b, M, D, eps, b.ln, b.ln_bytes, stream));
 #undef OV_TRY

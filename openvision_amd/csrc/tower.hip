@@ -453,10 +453,17 @@ extern "C" size_t ov_block_backward_workspace_bytes(const ov_tower_cfg* cfg, int
 
 // saved activations of one layer: [x | qkv | attention out | x1 | ln_1 out | ln_2 out | c_fc pre-activation | c_fc activation],
 // 8 D + 2 mlp_pad bf16 per token (288 GB of HBM: keep, do not recompute)
+// + per layer the attention's row log-sum-exp, fp32 [B * heads][L rounded up to 32] (ov_attention_lse; used by the backward where the
+// resident kernel applies: head_dim 64, L <= 288)
 static inline size_t saved_per_token(const ov_tower_cfg& c) { return (size_t)8 * c.width + 2 * (size_t)c.mlp_pad; }
+static inline size_t saved_lse_elems(const ov_tower_cfg& c, int B, int L) {      // in bf16 elements, a multiple of 8 (16-byte sections)
+    return ((size_t)2 * B * c.heads * ((L + 31) / 32 * 32) + 7) / 8 * 8;
+}
+static inline size_t saved_per_layer(const ov_tower_cfg& c, int B, int L) { return (size_t)B * L * saved_per_token(c) + saved_lse_elems(c, B, L); }
+static inline bool saved_lse_used(const ov_tower_cfg& c, int L) { return c.width / c.heads == 64 && (L + 31) / 32 * 32 <= 288; }
 extern "C" size_t ov_tower_saved_bytes(const ov_tower* t, int B, int L) {
     if (!t || B <= 0 || L <= 0) return 0;
-    return (size_t)t->cfg.layers * B * L * saved_per_token(t->cfg) * sizeof(ov_bf16);
+    return (size_t)t->cfg.layers * saved_per_layer(t->cfg, B, L) * sizeof(ov_bf16);
 }
 
 extern "C" int ov_tower_forward_saving(const ov_tower* t, ov_bf16* x, ov_bf16* saved, int B, int L, void* workspace,
@@ -470,7 +477,8 @@ extern "C" int ov_tower_forward_saving(const ov_tower* t, ov_bf16* x, ov_bf16* s
     const int64_t M = (int64_t)B * L;
     const float scale = 1.0f / sqrtf((float)hd);              // (every intermediate lands in `saved`: the workspace stays unused)
     const int gelu = c.gelu_tanh ? OV_EPI_BIAS_GELU_TANH : OV_EPI_BIAS_GELU_ERF;
-    const size_t spt = saved_per_token(c);
+    const size_t spl = saved_per_layer(c, B, L);
+    const bool keep_lse = saved_lse_used(c, L);
     for (int i = 0; i < c.layers; ++i)
         if (!t->set[i] || t->blocks[i].qkv_colsum || t->blocks[i].fc_colsum) return OV_ERR_INVALID;   // the module's own weights
     // layer i reads its input from its own saved slot and writes its output straight into layer i+1's slot (the last one into x):
@@ -479,7 +487,7 @@ extern "C" int ov_tower_forward_saving(const ov_tower* t, ov_bf16* x, ov_bf16* s
     if (e != hipSuccess) return OV_ERR_HIP - (int)e;
     for (int i = 0; i < c.layers; ++i) {
         const ov_block_weights& w = t->blocks[i];
-        ov_bf16* sx = saved + (size_t)i * M * spt;
+        ov_bf16* sx = saved + (size_t)i * spl;
         ov_bf16* sqkv = sx + (size_t)M * D;
         ov_bf16* so = sqkv + (size_t)M * 3 * D;
         ov_bf16* sx1 = so + (size_t)M * D;
@@ -487,12 +495,14 @@ extern "C" int ov_tower_forward_saving(const ov_tower* t, ov_bf16* x, ov_bf16* s
         ov_bf16* sn2 = sn1 + (size_t)M * D;
         ov_bf16* spre = sn2 + (size_t)M * D;
         ov_bf16* sact = spre + (size_t)M * c.mlp_pad;
-        ov_bf16* y = i + 1 < c.layers ? saved + (size_t)(i + 1) * M * spt : x;
+        float* slse = (float*)(sact + (size_t)M * c.mlp_pad);
+        ov_bf16* y = i + 1 < c.layers ? saved + (size_t)(i + 1) * spl : x;
         int rc;
         // the same operator sequence as run_block, with qkv / attention output / x1 written where the backward will read them
         if ((rc = ov_layernorm(sx, OV_BF16, D, w.ln1_w, w.ln1_b, sn1, OV_BF16, D, M, D, c.ln_eps, stream))) return rc;
         if ((rc = ov_gemm(sn1, D, w.qkv_w, D, w.qkv_b, sqkv, 3 * D, M, 3 * D, D, OV_EPI_BIAS, nullptr, 0, 0, 0, 0, stream))) return rc;
-        if ((rc = ov_attention(sqkv, 3 * D, so, D, B, L, H, hd, scale, stream))) return rc;
+        rc = keep_lse ? ov_attention_lse(sqkv, 3 * D, so, D, slse, B, L, H, hd, scale, stream) : ov_attention(sqkv, 3 * D, so, D, B, L, H, hd, scale, stream);
+        if (rc) return rc;
         if ((rc = ov_gemm(so, D, w.out_w, D, w.out_b, sx1, D, M, D, D, OV_EPI_BIAS_RESIDUAL, sx, D, 0, 0, 0, stream))) return rc;
         if ((rc = ov_layernorm(sx1, OV_BF16, D, w.ln2_w, w.ln2_b, sn2, OV_BF16, D, M, D, c.ln_eps, stream))) return rc;
         if ((rc = ov_gemm_keep(sn2, D, w.fc_w, D, w.fc_b, sact, c.mlp_pad, spre, c.mlp_pad, M, c.mlp_pad, D, gelu, stream))) return rc;
@@ -516,7 +526,7 @@ extern "C" int ov_tower_backward(const ov_tower* t, const ov_bf16* saved, ov_bf1
     for (int i = 0; i < c.layers; ++i)
         if (!t->set[i]) return OV_ERR_INVALID;
     for (int i = c.layers - 1; i >= 0; --i) {                     // dx holds d(block output) on entry and d(block input) on exit
-        const ov_bf16* sx = saved + (size_t)i * M * saved_per_token(c);
+        const ov_bf16* sx = saved + (size_t)i * saved_per_layer(c, B, L);
         ov_block_saved sv;
         sv.qkv = sx + (size_t)M * D;
         sv.attn_out = sv.qkv + (size_t)M * 3 * D;
@@ -525,6 +535,7 @@ extern "C" int ov_tower_backward(const ov_tower* t, const ov_bf16* saved, ov_bf1
         sv.ln2_out = sv.ln1_out + (size_t)M * D;
         sv.fc_pre = sv.ln2_out + (size_t)M * D;
         sv.fc_act = sv.fc_pre + (size_t)M * c.mlp_pad;
+        sv.attn_lse = saved_lse_used(c, L) ? (const float*)(sv.fc_act + (size_t)M * c.mlp_pad) : nullptr;
         const int rc = ov_block_backward(&c, &t->blocks[i], sx, &sv, dx, dx, &grads[i], B, L, workspace, workspace_bytes, stream);
         if (rc) return rc;
     }

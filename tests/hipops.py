@@ -236,6 +236,27 @@ def attention_backward(qkv, out, dout, B, L, H, hd=64):
     return dqkv
 
 
+def attention_lse(qkv, B, L, H, hd=64):
+    """ov_attention_lse: (out, lse [B*H, L rounded up to 32] fp32 in log2 units)."""
+    lib = _lib.load()
+    out = torch.empty(B * L, H * hd, dtype=torch.bfloat16, device=qkv.device)
+    lse = torch.full((B * H, (L + 31) // 32 * 32), float("nan"), dtype=torch.float32, device=qkv.device)
+    check(lib.ov_attention_lse(ptr(qkv), qkv.stride(0), ptr(out), out.stride(0), ptr(lse), B, L, H, hd, hd ** -0.5, stream_ptr()),
+          "ov_attention_lse")
+    return out, lse
+
+
+def attention_backward_saved(qkv, out, dout, lse, B, L, H, hd=64):
+    lib = _lib.load()
+    dqkv = torch.empty_like(qkv)
+    nb = lib.ov_attention_backward_workspace_bytes(B, L, H, hd)
+    ws = torch.empty(nb + 256, dtype=torch.uint8, device=qkv.device)
+    check(lib.ov_attention_backward_saved(ptr(qkv), qkv.stride(0), ptr(out), out.stride(0), ptr(dout), dout.stride(0), ptr(dqkv),
+                                          dqkv.stride(0), ptr(lse), B, L, H, hd, hd ** -0.5, ptr(ws), nb, stream_ptr()),
+          "ov_attention_backward_saved")
+    return dqkv
+
+
 def gemm_tn_batched(p, q, chunk, sums=False):
     """ov_gemm_tn_batched: partials [batch, NI, NJ] bf16 of P^T Q over row ranges of `chunk` contraction rows
     (sums=True: and the fp32 [batch, NI] column sums of P over the same ranges)."""

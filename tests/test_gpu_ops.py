@@ -408,6 +408,26 @@ def test_attention_backward_vs_oracle(B, L, H):
     assert torch.equal(again, dqkv)                                       # deterministic
 
 
+@pytest.mark.parametrize("B,L,H", [(2, 257, 4), (3, 80, 8), (1, 33, 2), (5, 288, 3), (2, 256, 16), (1, 1, 1)])
+def test_attention_keeps_the_row_lse_for_the_backward(B, L, H):
+    """ov_attention_lse = ov_attention plus the row log-sum-exp (log2 units) of the scaled scores; ov_attention_backward_saved with it
+    skips its own score pass.  The output is bitwise ov_attention's, the lse matches fp64 logsumexp, and the gradients match the
+    recomputing backward to the bf16 resolution of dS (the two lse differ in the last fp32 bits only)."""
+    qkv = bf(rnd(B * L, 3 * H * 64, seed=60)).to(DEV)
+    dout = bf(rnd(B * L, H * 64, seed=61)).to(DEV)
+    out, lse = H_.attention_lse(qkv, B, L, H)
+    assert torch.equal(out, H_.attention(qkv, B, L, H))
+    q, k = [t.view(B, L, H, 64).transpose(1, 2).double() for t in qkv.view(B, L, 3 * H * 64).split(H * 64, dim=-1)[:2]]
+    want = torch.logsumexp(q @ k.transpose(-1, -2) * 0.125, dim=-1) / np.log(2.0)          # [B, H, L], log2 units
+    got = lse.view(B, H, -1)[:, :, :L].double()
+    assert float((got - want).abs().max()) < 2e-5
+    a = H_.attention_backward_saved(qkv, out, dout, lse, B, L, H).float()
+    b = H_.attention_backward(qkv, out, dout, B, L, H).float()
+    assert float((a - b).abs().max()) <= 2 ** -7 * float(b.abs().max()) + 1e-6
+    with pytest.raises(H_._lib.OvhipError):
+        H_.attention_lse(bf(rnd(2 * 300, 3 * 64, seed=1)).to(DEV), 2, 300, 1)          # beyond the resident backward's L
+
+
 @pytest.mark.parametrize("B,L,H,hd", [(2, 257, 4, 72), (2, 257, 3, 80), (1, 40, 2, 72), (1, 300, 2, 80), (1, 65, 2, 32)])
 def test_attention_backward_other_head_dims(B, L, H, hd):
     """Head dims 72 (So400m) and 80 (H/14) go through the streaming kernels with the d axis zero-padded to 96 in LDS."""
