@@ -14,3 +14,12 @@ for _ in range(10): H.attention_backward(qkv, out, dout, B, L, Hh)
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 10
 print(f"attention_backward B {B} L {L} H {Hh}: {ms:.3f} ms = {10.0 * B * Hh * L * L * 64 / ms / 1e9:.0f} TFLOP/s (minimal 5 products)")
+if L <= 288:
+    out, lse = H.attention_lse(qkv, B, L, Hh)
+    for _ in range(3): H.attention_backward_saved(qkv, out, dout, lse, B, L, Hh)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(10): H.attention_backward_saved(qkv, out, dout, lse, B, L, Hh)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    print(f"attention_backward_saved (row lse kept by the forward): {ms:.3f} ms = {10.0 * B * Hh * L * L * 64 / ms / 1e9:.0f} TFLOP/s")
