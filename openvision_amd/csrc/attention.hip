@@ -297,7 +297,10 @@ __device__ __forceinline__ u32x2_t tr_read_off(unsigned addr) {
 // DEEP = workgroups of <= 8 waves (2 per SIMD, 256 VGPRs each): both K tiles of the next step are fetched behind the S MFMAs
 // and all V fragments of a step are in flight from its start.
 // OUT8: e4m3 output with a static scale (fp8 path: feeds the out-proj GEMM without a bf16 round trip); same 8 stores per head.
-template <bool DEEP, bool OUT8>
+// LSE: also store every query row's log-sum-exp (a.lse; training forward).  A template parameter, not a test of the pointer: a branch
+// between the stores and the vmcnt wait that names the prefetched Q registers would let hipcc copy those registers at the merge
+// point BEFORE the wait (it did: nondeterministic outputs).
+template <bool DEEP, bool OUT8, bool LSE = false>
 __global__ __launch_bounds__(DEEP ? 512 : 640, DEEP ? 2 : 3) void attn_fwd_hd64_persist(const AttnPArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -631,20 +634,18 @@ __global__ __launch_bounds__(DEEP ? 512 : 640, DEEP ? 2 : 3) void attn_fwd_hd64_
             OV_ST16(o0, 0, 0) OV_ST16(o0, 1, 32) OV_ST16(o1, 0, 64) OV_ST16(o1, 1, 96)
 #undef OV_ST16
         }
-        // everything but this head's stores (8 dword stores with e4m3 output, 4 dwordx4 stores otherwise) has completed
-        if (OUT8) {
-            asm volatile("s_waitcnt vmcnt(8)" : "+v"(qn[0]), "+v"(qn[1]), "+v"(qn[2]), "+v"(qn[3]) :: "memory");
-        } else if (a.lse != nullptr) {
+        if (LSE && !OUT8) {
             // kept for the backward (ov_attention_backward_saved): m and l are the same in both half-waves, rows past L repeat row
             // L - 1 (clamped Q row): duplicate stores of one value.  One more store behind the four of the output.
             const float v = m + __builtin_amdgcn_logf(l);                                                      // v_log_f32 = log2
             const float* lb = a.lse + (int64_t)bh * KC;                                                         // uniform
             const unsigned loff = row_offset(1, 0, 4u);
             asm volatile("global_store_dword %0, %1, %2" :: "v"(loff), "v"(v), "s"(lb) : "memory");
-            asm volatile("s_waitcnt vmcnt(5)" : "+v"(qn[0]), "+v"(qn[1]), "+v"(qn[2]), "+v"(qn[3]) :: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(4)" : "+v"(qn[0]), "+v"(qn[1]), "+v"(qn[2]), "+v"(qn[3]) :: "memory");
         }
+        // everything but this head's stores (8 dword stores with e4m3 output, 4 dwordx4 stores otherwise, + 1 with LSE) has completed
+        if (OUT8) asm volatile("s_waitcnt vmcnt(8)" : "+v"(qn[0]), "+v"(qn[1]), "+v"(qn[2]), "+v"(qn[3]) :: "memory");
+        else if (LSE) asm volatile("s_waitcnt vmcnt(5)" : "+v"(qn[0]), "+v"(qn[1]), "+v"(qn[2]), "+v"(qn[3]) :: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" : "+v"(qn[0]), "+v"(qn[1]), "+v"(qn[2]), "+v"(qn[3]) :: "memory");
     }
 }
 
@@ -1083,6 +1084,10 @@ int attention_impl(const ov_bf16* qkv, int64_t ld_qkv, ov_bf16* out, int64_t ld_
                 e = hipFuncSetAttribute((const void*)attn_fwd_hd64_persist<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e == hipSuccess)
                 e = hipFuncSetAttribute((const void*)attn_fwd_hd64_persist<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute((const void*)attn_fwd_hd64_persist<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute((const void*)attn_fwd_hd64_persist<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return OV_ERR_HIP - (int)e;
             attr2.mark(dev_attr2);
         }
@@ -1097,9 +1102,11 @@ int attention_impl(const ov_bf16* qkv, int64_t ld_qkv, ov_bf16* out, int64_t ld_
         const dim3 pg((unsigned)grid), pb(a.nqt * 64);
         if (a.nqt <= 8) {
             if (out8) hipLaunchKernelGGL((attn_fwd_hd64_persist<true, true>), pg, pb, smem, (hipStream_t)stream, p);
+            else if (lse) hipLaunchKernelGGL((attn_fwd_hd64_persist<true, false, true>), pg, pb, smem, (hipStream_t)stream, p);
             else hipLaunchKernelGGL((attn_fwd_hd64_persist<true, false>), pg, pb, smem, (hipStream_t)stream, p);
         } else {
             if (out8) hipLaunchKernelGGL((attn_fwd_hd64_persist<false, true>), pg, pb, smem, (hipStream_t)stream, p);
+            else if (lse) hipLaunchKernelGGL((attn_fwd_hd64_persist<false, false, true>), pg, pb, smem, (hipStream_t)stream, p);
             else hipLaunchKernelGGL((attn_fwd_hd64_persist<false, false>), pg, pb, smem, (hipStream_t)stream, p);
         }
         OV_LAUNCH_CHECK();

@@ -622,6 +622,31 @@ def test_training_loss_decreases_tiny(tiny):
     assert sum(b < a for a, b in zip(losses, losses[1:])) >= 6, losses
 
 
+@pytest.mark.parametrize("name,size,B", [("vit-tiny-patch16-160", 160, 8), ("vit-large-patch14-224", 224, 12)])
+def test_training_step_is_bitwise_repeatable(name, size, B):
+    """No weight update between them: four training steps (forward keeping every intermediate incl. the attention's row lse, loss,
+    backward) must give the SAME loss and the same gradient of every parameter, bit for bit.  Every kernel on the path is
+    deterministic by construction (fixed-order reductions, no atomics); what this catches is a hand-counted wait that no longer
+    covers a load -- the attention forward once produced run-to-run differences of 15 % in the gradient norm that way (a runtime
+    branch between its stores and the wait on the prefetched Q rows)."""
+    from openvision_amd import training
+    from openvision_amd.loss import ClipLoss
+    cfg = preset(name)
+    m = create_model(cfg, device=DEV, state_dict=synth.make_state_dict(cfg, variant="sharp"))
+    img, tok = synth.make_structured_images(B, size, seed=7).to(DEV), synth.make_captions(B, seed=7).to(DEV)
+    first = None
+    for it in range(4):
+        m.zero_grad(set_to_none=True)
+        loss = ClipLoss()(*training.clip_forward(m, img, tok))
+        loss.backward()
+        cur = [loss.detach().clone()] + [p.grad.detach().clone() for p in m.parameters()]
+        if first is None:
+            first = cur
+        else:
+            bad = [i for i, (a, b) in enumerate(zip(first, cur)) if not torch.equal(a, b)]
+            assert not bad, (it, len(bad), bad[:5])
+
+
 def _ddp_rank(rank, ws, store, q):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
