@@ -226,6 +226,34 @@ def block_backward(cfg, weights, x, dy, B, L):
     return dx, grads
 
 
+def tower1_forward_backward(cfg, weights, x, dy, B, L):
+    """A one-layer tower through ov_tower_forward_saving + ov_tower_backward (every forward intermediate kept, fused backward
+    epilogues): returns (y bf16, dx bf16, grads dict)."""
+    import ctypes as C
+    lib = _lib.load()
+    names = ("ln1_w", "ln1_b", "qkv_w", "qkv_b", "out_w", "out_b", "ln2_w", "ln2_b", "fc_w", "fc_b", "proj_w", "proj_b")
+    handle = lib.ov_tower_create(C.byref(cfg))
+    assert handle
+    try:
+        wst = _lib.BlockWeights(*[C.c_void_p(weights[n].data_ptr()) for n in names], None, None)
+        check(lib.ov_tower_set_block(handle, 0, C.byref(wst)), "ov_tower_set_block")
+        y = x.clone()
+        saved = torch.empty(lib.ov_tower_saved_bytes(handle, B, L) + 256, dtype=torch.uint8, device=x.device)
+        nb = lib.ov_tower_workspace_bytes(handle, B, L)
+        ws = torch.empty(nb + 256, dtype=torch.uint8, device=x.device)
+        check(lib.ov_tower_forward_saving(handle, ptr(y), ptr(saved), B, L, ptr(ws), nb, stream_ptr()), "ov_tower_forward_saving")
+        grads = {n: torch.empty_like(weights[n]) for n in names}
+        garr = (_lib.BlockGrads * 1)(_lib.BlockGrads(*[C.c_void_p(grads[n].data_ptr()) for n in names]))
+        dx = dy.clone()
+        nb2 = lib.ov_tower_backward_workspace_bytes(handle, B, L)
+        ws2 = torch.empty(nb2 + 256, dtype=torch.uint8, device=x.device)
+        check(lib.ov_tower_backward(handle, ptr(saved), ptr(dx), garr, B, L, ptr(ws2), nb2, stream_ptr()), "ov_tower_backward")
+        torch.cuda.synchronize()
+    finally:
+        lib.ov_tower_destroy(handle)
+    return y, dx, grads
+
+
 def attention_backward(qkv, out, dout, B, L, H, hd=64):
     lib = _lib.load()
     dqkv = torch.empty_like(qkv)

@@ -483,6 +483,29 @@ def _block_case(D, heads, mlp, B, L, tanh, seed, mlp_pad=None):
     return names, sd, dev, x, dy
 
 
+@pytest.mark.parametrize("D,heads,mlp,B,L,tanh", [(1024, 16, 4096, 72, 257, False), (768, 12, 3072, 256, 80, True), (192, 3, 768, 4, 101, False)])
+def test_kept_activation_backward_matches_the_recomputing_backward(D, heads, mlp, B, L, tanh):
+    """ov_tower_forward_saving + ov_tower_backward (pre-activation from the GELU epilogue's second output, GELU derivative inside
+    dy Wproj, bias gradients out of the TN kernel, attention row lse from the forward) against ov_block_backward on the block input
+    alone (everything recomputed, element-wise GELU backward with the A&S erf): the same gradients up to the bf16 resolution of the
+    intermediates.  The first two shapes are large enough for the PERSISTENT kernels (> 256 tiles per product), which the model-level
+    gradient tests (Tiny, small batches) never reach."""
+    from openvision_amd import _lib as L_
+    names, sd, dev, x, dy = _block_case(D, heads, mlp, B, L, tanh, 70)
+    cfg = L_.TowerCfg(D, 1, heads, mlp, mlp, int(tanh), 1e-6)
+    xd, dyd = x.reshape(B * L, D).to(DEV), dy.reshape(B * L, D).to(DEV)
+    _, dx_k, g_k = H_.tower1_forward_backward(cfg, dev, xd, dyd, B, L)
+    dx_r, g_r = H_.block_backward(cfg, dev, xd, dyd, B, L)
+    def close(a, b, what):
+        a, b = a.float(), b.float()
+        err = float((a - b).abs().max())
+        rel = float((a - b).norm() / b.norm().clamp_min(1e-20))
+        assert err < 2e-2 * float(b.abs().max()) + 1e-6 and rel < 1e-2, (what, err, float(b.abs().max()), rel)
+    close(dx_k, dx_r, "dx")
+    for k in names:
+        close(g_k[k], g_r[k], k)
+
+
 @pytest.mark.parametrize("D,heads,mlp,B,L,tanh", [(192, 3, 768, 2, 101, False), (1024, 16, 4096, 2, 257, False), (768, 12, 3072, 3, 80, True),
                                                   (384, 6, 1536, 1, 700, False)])
 def test_block_backward_vs_oracle(D, heads, mlp, B, L, tanh):
