@@ -443,6 +443,8 @@ __global__ __launch_bounds__(DEEP ? 512 : 640, DEEP ? 2 : 3) void attn_fwd_hd64_
             for (int st = 0; st < 4; ++st) sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfb[st], qf[st], sb, 0, 0, 0);
             if (!DEEP) read_vt();
             if (kt + 2 < nk_tiles) load_k(kfa, kt + 2);                // next step's first tile, fetched under the softmax
+            else if (DEEP) asm volatile("s_nop 7" : "+v"(sb));         // last step of an even tile count: nothing else separates the sb
+                                                                       // MFMAs from tile_max's inline-asm reads (see the single-tile step)
             if (DEEP && kt + 3 < nk_tiles) load_k(kfb, kt + 3);
             mask_tail(sb, kt + 1);
             float mx = fmaxf(tile_max(sa), tile_max(sb));
@@ -559,6 +561,12 @@ __global__ __launch_bounds__(DEEP ? 512 : 640, DEEP ? 2 : 3) void attn_fwd_hd64_
 #pragma unroll
             for (int st = 0; st < 4; ++st) sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfa[st], qf[st], sa, 0, 0, 0);
             mask_tail(sa, kt);
+            // tile_max reads the accumulator from inline asm (v_max3): the wait states an MFMA result needs before a VALU read are
+            // not inserted in front of inline asm, and when the tile is full (mask_tail reads nothing) no other instruction separates
+            // the two here.  (In the pair loop a dozen LDS reads and the other tile's maximum sit in between.)  Read too early the
+            // maximum is some older value: harmless for the softmax -- any shift m gives the same result up to rounding -- but
+            // the output then differs in the last bit from run to run (seen in an experiment of round 2 with this very pattern).
+            asm volatile("s_nop 15" : "+v"(sa));
             float mx = tile_max(sa);
             {
                 const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
