@@ -1076,7 +1076,7 @@ int attention_impl(const ov_bf16* qkv, int64_t ld_qkv, ov_bf16* out, int64_t ld_
     const int lp = a.nqt * 32;
     static int force_v1 = -1;
     if (force_v1 < 0) { const char* e = getenv("OVHIP_ATTN_V1"); force_v1 = (e && e[0] == '1') ? 1 : 0; }
-    if (lp <= 320 && !force_v1 && (int64_t)L * ld_qkv * 2 < 0x7fffffffLL && (int64_t)L * ld_out * 2 < 0x7fffffffLL) {
+    if (lp <= 320 && (!force_v1 || lse) && (int64_t)L * ld_qkv * 2 < 0x7fffffffLL && (int64_t)L * ld_out * 2 < 0x7fffffffLL) {   // (lse: only this kernel keeps it)
         AttnPArgs p;
         p.qkv = qkv; p.ldq = ld_qkv; p.out = out; p.ldo = ld_out;
         p.L = L; p.H = H; p.nqt = a.nqt; p.KC = lp; p.nheads = B * H; p.scale_log2 = a.scale_log2; p.out_amax = out_amax; p.amax_next = amax_next; p.lse = lse;
