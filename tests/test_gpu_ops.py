@@ -483,7 +483,8 @@ def _block_case(D, heads, mlp, B, L, tanh, seed, mlp_pad=None):
     return names, sd, dev, x, dy
 
 
-@pytest.mark.parametrize("D,heads,mlp,B,L,tanh", [(1024, 16, 4096, 72, 257, False), (768, 12, 3072, 256, 80, True), (192, 3, 768, 4, 101, False)])
+@pytest.mark.parametrize("D,heads,mlp,B,L,tanh", [(1024, 16, 4096, 72, 257, False), (768, 12, 3072, 256, 80, True), (192, 3, 768, 4, 101, False),
+                                                  (1152, 16, 4304, 6, 257, False), (384, 6, 1536, 2, 700, False), (1280, 16, 5120, 3, 257, False)])
 def test_kept_activation_backward_matches_the_recomputing_backward(D, heads, mlp, B, L, tanh):
     """ov_tower_forward_saving + ov_tower_backward (pre-activation from the GELU epilogue's second output, GELU derivative inside
     dy Wproj, bias gradients out of the TN kernel, attention row lse from the forward) against ov_block_backward on the block input
@@ -491,8 +492,9 @@ def test_kept_activation_backward_matches_the_recomputing_backward(D, heads, mlp
     intermediates.  The first two shapes are large enough for the PERSISTENT kernels (> 256 tiles per product), which the model-level
     gradient tests (Tiny, small batches) never reach."""
     from openvision_amd import _lib as L_
-    names, sd, dev, x, dy = _block_case(D, heads, mlp, B, L, tanh, 70)
-    cfg = L_.TowerCfg(D, 1, heads, mlp, mlp, int(tanh), 1e-6)
+    mlp_pad = (mlp + 63) // 64 * 64            # So400m: 4304 -> 4352 (zero rows / columns); head dims 72 and 80: no kept lse; L = 700: streaming
+    names, sd, dev, x, dy = _block_case(D, heads, mlp, B, L, tanh, 70, mlp_pad=mlp_pad)
+    cfg = L_.TowerCfg(D, 1, heads, mlp, mlp_pad, int(tanh), 1e-6)
     xd, dyd = x.reshape(B * L, D).to(DEV), dy.reshape(B * L, D).to(DEV)
     _, dx_k, g_k = H_.tower1_forward_backward(cfg, dev, xd, dyd, B, L)
     dx_r, g_r = H_.block_backward(cfg, dev, xd, dyd, B, L)
