@@ -18,6 +18,7 @@ attention backward with d zero-padded to 96, an MLP width that is not a multiple
 """
 from __future__ import annotations
 
+import os
 import ctypes as C
 from typing import List, Tuple
 
@@ -80,17 +81,17 @@ class _Pool:
 def _train_state(transformer):
     st = getattr(transformer, "_ovhip_train_state", None)
     if st is None:
-        st = {"sig": None, "keep": None, "pool": _Pool()}
+        st = {"chunks": {}, "pool": _Pool()}            # chunks: (first layer, last layer + 1) -> {"sig", "keep"}
         object.__setattr__(transformer, "_ovhip_train_state", st)
     return st
 
 
-def _packed_blocks(transformer, params, mlp: int, mlp_pad: int):
+def _packed_blocks(transformer, params, mlp: int, mlp_pad: int, span=(0, -1)):
     """Kernel-layout copies of every block's parameters, rebuilt only when a parameter changed: keyed, as the inference path's
     cache is, by (data_ptr, _version) of the sources (an optimiser step bumps _version; frozen weights -- gradient ascent on the
     inputs, ov-gradient-ascent.py -- hit the cache every step).  `model.invalidate_packed()` drops it (writes through .data)."""
     from .model import _PACK_EPOCH
-    st = _train_state(transformer)
+    st = _train_state(transformer)["chunks"].setdefault(tuple(span), {"sig": None, "keep": None})
     sig = (_PACK_EPOCH[0], mlp_pad) + tuple((p.data_ptr(), p._version, p.dtype, p.device) for p in params)
     if st["sig"] != sig:
         st["keep"] = [_pad_mlp([_device_copy(p) for p in params[12 * i:12 * i + 12]], mlp, mlp_pad) for i in range(len(params) // 12)]
@@ -99,12 +100,13 @@ def _packed_blocks(transformer, params, mlp: int, mlp_pad: int):
 
 
 class _TowerFn(torch.autograd.Function):
-    """Transformer.forward (transformer.py:355-366) as one autograd node over all its blocks."""
+    """Transformer.forward (transformer.py:355-366) as one autograd node over the blocks [lo, hi) (all of them by default; several
+    consecutive nodes when ``tower_forward`` is asked for chunks, so that parameter gradients become available chunk by chunk)."""
 
     @staticmethod
-    def forward(ctx, transformer, x, *params):
+    def forward(ctx, transformer, lo, hi, x, *params):
         lib = _lib.load()
-        blocks = list(transformer.resblocks)
+        blocks = list(transformer.resblocks)[lo:hi]
         b0 = blocks[0]
         d, heads, mlp, mlp_pad = b0.attn.embed_dim, b0.attn.num_heads, b0.mlp_dim, b0.mlp_pad
         if d % 64 or d % heads or (d // heads) % 8 or d // heads > 96:
@@ -116,7 +118,7 @@ class _TowerFn(torch.autograd.Function):
             raise _lib.OvhipError("ov_tower_create failed")
         pool = _train_state(transformer)["pool"]
         try:
-            keep = _packed_blocks(transformer, params, mlp, mlp_pad)
+            keep = _packed_blocks(transformer, params, mlp, mlp_pad, (lo, hi))
             for i, ts in enumerate(keep):
                 bw = _lib.BlockWeights(*[C.c_void_p(t.data_ptr()) for t in ts], None, None)
                 check(lib.ov_tower_set_block(handle, i, C.byref(bw)), "ov_tower_set_block")
@@ -163,7 +165,7 @@ class _TowerFn(torch.autograd.Function):
         for gs in grads:
             gs[8], gs[9], gs[10] = gs[8][:mlp], gs[9][:mlp], gs[10][:, :mlp]
         flat = [g.to(ctx.p_dtypes[12 * i + j]) for i, gs in enumerate(grads) for j, g in enumerate(gs)]
-        return (None, dx.view(bsz, seq, d).to(ctx.x_dtype), *flat)
+        return (None, None, None, dx.view(bsz, seq, d).to(ctx.x_dtype), *flat)
 
 
 def _round_up(x: int, m: int) -> int:
@@ -248,12 +250,28 @@ class _LayerNormFn(torch.autograd.Function):
         return dx.view(shape).to(xd), dg.to(wd), db.to(bd), None
 
 
+CHUNK_LAYERS = [max(0, int(os.environ.get("OVHIP_TRAIN_CHUNK_LAYERS", "0") or 0))]   # > 0: towers run as consecutive autograd nodes of that many blocks
+
+
+def set_backward_chunk_layers(n: int) -> None:
+    """Run every tower as consecutive autograd nodes of ``n`` blocks each (0 = one node per tower, the default).  The arithmetic
+    is unchanged; what changes is WHEN parameter gradients exist: after each chunk's backward instead of after the whole tower's,
+    which is what lets ``FusedAdamW.overlap_gradient_exchange`` start a bucket's all-reduce while earlier blocks are still in
+    their backward (the reference leaves this to DistributedDataParallel's bucket hooks)."""
+    CHUNK_LAYERS[0] = max(0, int(n))
+
+
 def tower_forward(transformer, x: torch.Tensor) -> torch.Tensor:
     """``transformer(x)`` with gradients: x [B, L, D] on the device -> same shape; d x and every block parameter receive grad."""
     if not x.is_cuda:
         raise _lib.OvhipError("training path: tensors must live on an MI355X device (no CPU fallback)")
-    params = [p for blk in transformer.resblocks for p in _block_tensors(blk)]
-    return _TowerFn.apply(transformer, x, *params)
+    blocks = list(transformer.resblocks)
+    step = CHUNK_LAYERS[0] if CHUNK_LAYERS[0] > 0 else len(blocks)
+    for lo in range(0, len(blocks), step):
+        hi = min(len(blocks), lo + step)
+        params = [p for blk in blocks[lo:hi] for p in _block_tensors(blk)]
+        x = _TowerFn.apply(transformer, lo, hi, x, *params)
+    return x
 
 
 def encode_image(model, image: torch.Tensor, normalize: bool = True) -> torch.Tensor:
@@ -387,6 +405,7 @@ class FusedAdamW:
                 want = g["grad"][o:o + p.numel()]
                 if p.grad is None or p.grad.data_ptr() != want.data_ptr():
                     p.grad = want.view(p.shape)
+        self._rearm()
 
     def _collect(self) -> None:
         """A ``.grad`` that autograd replaced instead of accumulating in place is copied back into its flat slot."""
@@ -405,10 +424,71 @@ class FusedAdamW:
             for s in range(0, n, per):
                 yield g["grad"][s:min(n, s + per)]
 
+    def overlap_gradient_exchange(self, world_size: int, group=None) -> None:
+        """Start each bucket's SUM all-reduce from autograd, as soon as the last parameter gradient that lies in the bucket has been
+        accumulated (post-accumulate-grad hooks), instead of after the whole backward -- DistributedDataParallel's bucket overlap
+        (the reference trainer: src/main_clip.py wraps the model the same way) on the flat buffers of this optimiser.  With
+        ``set_backward_chunk_layers(n)`` the towers' gradients arrive chunk by chunk, so the exchange of the later blocks' buckets
+        runs under the backward of the earlier ones.  ``all_reduce_gradients`` then only launches what is left and waits.  Call
+        ``zero_grad()`` (this class's) before every backward: it re-arms the buckets."""
+        self._ov = dict(world=int(world_size), group=group, works=[], pending=[], launched=[])
+        self._ov_buckets = []                                   # (group index, start, stop)
+        per = max(1, self.bucket_bytes // 4)
+        for gi, g in enumerate(self.groups):
+            n = g["grad"].numel()
+            self._ov_buckets += [(gi, s, min(n, s + per)) for s in range(0, n, per)]
+        self._ov_members = [[] for _ in self._ov_buckets]       # parameters overlapping each bucket
+        for gi, g in enumerate(self.groups):
+            for pi, ((_, p), o) in enumerate(zip(g["params"], g["offs"])):
+                mine = [bi for bi, (bg, s, e) in enumerate(self._ov_buckets) if bg == gi and s < o + p.numel() and o < e]
+                for bi in mine:
+                    self._ov_members[bi].append((gi, pi))
+                p.register_post_accumulate_grad_hook(self._make_hook(gi, pi, o, mine))
+        self._rearm()
+
+    def _rearm(self) -> None:
+        ov = getattr(self, "_ov", None)
+        if ov is not None:
+            ov["works"], ov["launched"] = [], [False] * len(self._ov_buckets)
+            ov["pending"] = [len(m) for m in self._ov_members]
+
+    def _launch_bucket(self, bi: int) -> None:
+        import torch.distributed as dist
+        ov = self._ov
+        gi, s, e = self._ov_buckets[bi]
+        ov["launched"][bi] = True
+        if ov["world"] > 1:
+            ov["works"].append(dist.all_reduce(self.groups[gi]["grad"][s:e], op=dist.ReduceOp.SUM, group=ov["group"], async_op=True))
+
+    def _make_hook(self, gi: int, pi: int, off: int, buckets):
+        def hook(p):
+            want = self.groups[gi]["grad"][off:off + p.numel()]
+            if p.grad is not None and p.grad.data_ptr() != want.data_ptr():      # autograd replaced the view: fold it back first
+                want.copy_(p.grad.detach().reshape(-1).float())
+                p.grad = want.view(p.shape)
+            ov = self._ov
+            for bi in buckets:
+                ov["pending"][bi] -= 1
+                if ov["pending"][bi] == 0 and not ov["launched"][bi]:
+                    self._launch_bucket(bi)
+        return hook
+
     def all_reduce_gradients(self, world_size: int, group=None) -> float:
         """SUM all-reduce of every bucket (RCCL when the backend is 'nccl'), all issued before any is waited for; returns the factor
-        (1 / world_size) that ``step(grad_scale=...)`` folds into the update instead of a separate averaging pass."""
+        (1 / world_size) that ``step(grad_scale=...)`` folds into the update instead of a separate averaging pass.  After
+        ``overlap_gradient_exchange`` most buckets are already in flight: the rest (parameters that received no gradient) is
+        launched here, then everything is waited for."""
         import torch.distributed as dist
+        ov = getattr(self, "_ov", None)
+        if ov is not None:
+            self._collect()
+            for bi in range(len(self._ov_buckets)):
+                if not ov["launched"][bi]:
+                    self._launch_bucket(bi)
+            for w in ov["works"]:
+                w.wait()
+            ov["works"] = []
+            return 1.0 / ov["world"]
         self._collect()
         if world_size > 1:
             works = [dist.all_reduce(b, op=dist.ReduceOp.SUM, group=group, async_op=True) for b in self.buckets()]

@@ -112,3 +112,59 @@ def test_bucketed_gradient_all_reduce_world_size_2():
     for n in want:
         ref = want[n].numpy() if n != "logit_scale" else np.float32(3.0 + 4.0)
         np.testing.assert_allclose(got[n], ref, rtol=1e-6, atol=1e-6, err_msg=n)
+
+
+def _overlap_worker(rank, ws, store, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    dist.init_process_group("gloo", init_method=f"file://{store}", rank=rank, world_size=ws)
+    from openvision_amd import preset, synth, training
+    from openvision_amd.model import create_model
+    cfg = preset("vit-tiny-patch16-160")
+    m = create_model(cfg, state_dict=synth.make_state_dict(cfg))
+    opt = training.FusedAdamW(m, lr=1e-3, bucket_bytes=1 << 20)
+    opt.overlap_gradient_exchange(ws)
+    nb = len(opt._ov_buckets)
+    res = []
+    for it in range(2):                                                       # two backward passes: the buckets re-arm in zero_grad
+        opt.zero_grad()
+        g = torch.Generator().manual_seed(1000 * it + 100 + rank)
+        coef = {n: torch.randn(p.shape, generator=g) for n, p in m.named_parameters()}
+        loss = sum((p * coef[n]).sum() for n, p in m.named_parameters())      # d loss / d p = coef: every hook fires during backward
+        loss.backward()
+        launched = sum(opt._ov["launched"])                                   # buckets already in flight when backward returns
+        scale = opt.all_reduce_gradients(ws)
+        res.append((launched, scale, {n: p.grad.clone().numpy() for n, p in m.named_parameters()} if rank == 0 else None))
+    q.put((rank, nb, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_gradient_exchange_world_size_2():
+    """FusedAdamW.overlap_gradient_exchange over gloo at world_size 2: every bucket's all-reduce is started from autograd's
+    post-accumulate hooks (all of them are in flight when backward returns), the sums are those of the plain exchange, and the
+    buckets re-arm for the next backward."""
+    ws = 2
+    ctx = mp.get_context("spawn")
+    with tempfile.TemporaryDirectory() as d:
+        q = ctx.Queue()
+        ps = [ctx.Process(target=_overlap_worker, args=(r, ws, os.path.join(d, "store"), q)) for r in range(ws)]
+        [p.start() for p in ps]
+        out = sorted((q.get(timeout=300) for _ in range(ws)), key=lambda r: r[0])
+        [p.join(60) for p in ps]
+    from openvision_amd import preset
+    from openvision_amd.model import create_model
+    m = create_model(preset("vit-tiny-patch16-160"))
+    for rank, nb, res in out:
+        assert nb > 5
+        for launched, scale, _ in res:
+            assert launched == nb and scale == 0.5
+    for it in range(2):
+        want = {}
+        for rank in range(ws):
+            g = torch.Generator().manual_seed(1000 * it + 100 + rank)
+            for n, p in m.named_parameters():
+                want[n] = want.get(n, 0) + torch.randn(p.shape, generator=g)
+        got = out[0][2][it][2]
+        for n in want:
+            np.testing.assert_allclose(got[n], want[n].numpy(), rtol=1e-6, atol=1e-6, err_msg=f"{it} {n}")

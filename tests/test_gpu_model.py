@@ -590,7 +590,7 @@ def test_training_soft_token_entry_gradient(tiny):
             tf = training.encode_text(tiny, sp, normalize=True)
             loss = -(tf * target.to(DEV)).sum(-1).mean()
             loss.backward()
-        st = tiny.transformer._ovhip_train_state
+        (st,) = tiny.transformer._ovhip_train_state["chunks"].values()      # one autograd node per tower: one packed chunk
         sig0 = st["sig"]
         training.encode_text(tiny, sp.detach(), normalize=True)
         assert st["sig"] is sig0                                   # cache hit: nothing re-packed
@@ -645,6 +645,27 @@ def test_training_step_is_bitwise_repeatable(name, size, B):
         else:
             bad = [i for i, (a, b) in enumerate(zip(first, cur)) if not torch.equal(a, b)]
             assert not bad, (it, len(bad), bad[:5])
+
+
+def test_chunked_tower_backward_is_bitwise_the_single_node_backward():
+    """training.set_backward_chunk_layers(n): the towers as consecutive autograd nodes of n blocks (gradients become available
+    chunk by chunk for the overlapped exchange) -- the same kernels on the same data: loss and every gradient bit for bit."""
+    from openvision_amd import training
+    from openvision_amd.loss import ClipLoss
+    cfg = preset("vit-tiny-patch16-160")
+    img, tok = synth.make_structured_images(8, 160, seed=9).to(DEV), synth.make_captions(8, seed=9).to(DEV)
+    outs = []
+    try:
+        for chunk in (0, 5, 1):
+            training.set_backward_chunk_layers(chunk)
+            m = create_model(cfg, device=DEV, state_dict=synth.make_state_dict(cfg, variant="sharp"))
+            loss = ClipLoss()(*training.clip_forward(m, img, tok))
+            loss.backward()
+            outs.append([loss.detach().clone()] + [p.grad.detach().clone() for p in m.parameters()])
+    finally:
+        training.set_backward_chunk_layers(0)
+    for other in outs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(outs[0], other))
 
 
 def _ddp_rank(rank, ws, store, q):
