@@ -424,14 +424,15 @@ class FusedAdamW:
             for s in range(0, n, per):
                 yield g["grad"][s:min(n, s + per)]
 
-    def overlap_gradient_exchange(self, world_size: int, group=None) -> None:
+    def overlap_gradient_exchange(self, world_size: int, group=None, always_collective: bool = False) -> None:
         """Start each bucket's SUM all-reduce from autograd, as soon as the last parameter gradient that lies in the bucket has been
         accumulated (post-accumulate-grad hooks), instead of after the whole backward -- DistributedDataParallel's bucket overlap
         (the reference trainer: src/main_clip.py wraps the model the same way) on the flat buffers of this optimiser.  With
         ``set_backward_chunk_layers(n)`` the towers' gradients arrive chunk by chunk, so the exchange of the later blocks' buckets
         runs under the backward of the earlier ones.  ``all_reduce_gradients`` then only launches what is left and waits.  Call
-        ``zero_grad()`` (this class's) before every backward: it re-arms the buckets."""
-        self._ov = dict(world=int(world_size), group=group, works=[], pending=[], launched=[])
+        ``zero_grad()`` (this class's) before every backward: it re-arms the buckets.  ``always_collective`` issues the collectives
+        in a world of one rank as well (exercises the RCCL calls on a single GPU)."""
+        self._ov = dict(world=int(world_size), group=group, works=[], pending=[], launched=[], force=bool(always_collective))
         self._ov_buckets = []                                   # (group index, start, stop)
         per = max(1, self.bucket_bytes // 4)
         for gi, g in enumerate(self.groups):
@@ -457,7 +458,7 @@ class FusedAdamW:
         ov = self._ov
         gi, s, e = self._ov_buckets[bi]
         ov["launched"][bi] = True
-        if ov["world"] > 1:
+        if ov["world"] > 1 or ov["force"]:             # force: issue the collective in a world of one rank too (RCCL path test)
             ov["works"].append(dist.all_reduce(self.groups[gi]["grad"][s:e], op=dist.ReduceOp.SUM, group=ov["group"], async_op=True))
 
     def _make_hook(self, gi: int, pi: int, off: int, buckets):

@@ -807,6 +807,58 @@ def _nccl_ws1_rank(store, q):
     dist.destroy_process_group()
 
 
+def _nccl_overlap_rank(store, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    from openvision_amd import training
+    from openvision_amd.loss import ClipLoss
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"file://{store}", rank=0, world_size=1, device_id=torch.device(DEV))
+    cfg = preset("vit-tiny-patch16-160")
+    img, tok = synth.make_structured_images(8, 160, seed=11).to(DEV), synth.make_captions(8, seed=11).to(DEV)
+    res = {}
+    for mode in ("plain", "overlap"):
+        m = create_model(cfg, device=DEV, state_dict=synth.make_state_dict(cfg, variant="sharp"))
+        opt = training.FusedAdamW(m, lr=1e-3, bucket_bytes=4 << 20)
+        if mode == "overlap":
+            training.set_backward_chunk_layers(4)
+            opt.overlap_gradient_exchange(1, always_collective=True)
+        opt.zero_grad()
+        loss = ClipLoss()(*training.clip_forward(m, img, tok))
+        loss.backward()
+        launched = sum(opt._ov["launched"]) if mode == "overlap" else 0
+        nb = len(opt._ov_buckets) if mode == "overlap" else 0
+        scale = opt.all_reduce_gradients(1)
+        opt.step(grad_scale=scale)
+        torch.cuda.synchronize()
+        res[mode] = (float(loss.detach()), launched, nb, {n: p.detach().float().cpu().numpy() for n, p in m.named_parameters()})
+        training.set_backward_chunk_layers(0)
+    q.put(res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_gradient_exchange_on_rccl_world_size_1():
+    """FusedAdamW.overlap_gradient_exchange with the collectives forced in a world of one rank on the 'nccl' backend: the RCCL
+    all-reduces are issued from autograd's hooks while the chunked backward is still running, on the one GPU there is.  Loss and the
+    UPDATED parameters (one AdamW step) must equal those of the plain sequence bit for bit (a sum over one rank is the identity)."""
+    import tempfile
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    with tempfile.TemporaryDirectory() as d:
+        q = ctx.Queue()
+        p = ctx.Process(target=_nccl_overlap_rank, args=(os.path.join(d, "store"), q))
+        p.start()
+        out = q.get(timeout=600)
+        p.join(120)
+    l0, _, _, p0 = out["plain"]
+    l1, launched, nb, p1 = out["overlap"]
+    assert l0 == l1 and nb >= 2 and launched == nb
+    for n in p0:
+        np.testing.assert_array_equal(p0[n], p1[n], err_msg=n)
+
+
 def test_rccl_branch_of_the_loss_at_world_size_1():
     """The RCCL ('nccl' backend) code path of the data-parallel loss -- all_gather_into_tensor in gather_features and
     reduce_scatter_tensor in the gathered-side gradient routing -- executed on the one GPU there is: a world of one rank, with
