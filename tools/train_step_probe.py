@@ -28,7 +28,21 @@ def fwd_only():
         fi, ft = m.encode_image(img.to(torch.bfloat16), True), m.encode_text(tok, True)
         return loss_fn(fi, ft, m.logit_scale.exp())
 
-for fn, label in ((fwd_only, "inference forward + loss"), (step, "training step (forward-saving + loss + backward)")):
+opt = None
+
+def full_step():
+    """forward keeping activations + InfoNCE + backward + FusedAdamW (global-norm clipping on), gradients in the optimiser's flat buffers"""
+    opt.zero_grad()
+    fi, ft, sc = training.clip_forward(m, img, tok)
+    loss = loss_fn(fi, ft, sc)
+    loss.backward()
+    opt.step(grad_scale=opt.all_reduce_gradients(1))
+    return loss
+
+for fn, label in ((fwd_only, "inference forward + loss"), (step, "training step (forward-saving + loss + backward)"),
+                  (full_step, "complete training step (+ FusedAdamW update, clipping on; weights re-packed every step)")):
+    if fn is full_step:
+        opt = training.FusedAdamW(m, lr=1e-6, clip_norm=1.0)
     fn(); torch.cuda.synchronize()
     n = 3
     t0 = time.perf_counter()
