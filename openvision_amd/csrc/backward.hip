@@ -104,8 +104,9 @@ __global__ __launch_bounds__(256) void colsum_partial(const unsigned int* __rest
 // out[split][n] = sum of partial rows [split * rows_per, (split + 1) * rows_per) (fixed order: wave w takes rows = w mod 4, eight
 // loads in flight, then the four waves are combined through LDS).  Block = 64 columns x 4 waves; grid (ceil(N / 64), nsplit).
 constexpr int RS_SPLIT = 32;
+// out_hi != NULL: single-split launches only; columns >= n_lo go to out_hi[n - n_lo] (two vectors out of one pass: dgamma | dbeta)
 __global__ __launch_bounds__(256) void rows_sum(const float* __restrict__ part, int64_t nrow, int N, int64_t stride, int64_t rows_per,
-                                                float* __restrict__ out) {
+                                                float* __restrict__ out, float* __restrict__ out_hi = nullptr, int n_lo = 0) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + lane;
@@ -125,22 +126,28 @@ __global__ __launch_bounds__(256) void rows_sum(const float* __restrict__ part, 
     }
     red[wave][lane] = s;
     __syncthreads();
-    if (wave == 0 && n < N) out[(int64_t)blockIdx.y * N + n] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+    if (wave == 0 && n < N) {
+        const float v = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+        if (out_hi != nullptr && n >= n_lo) out_hi[n - n_lo] = v;
+        else out[(int64_t)blockIdx.y * N + n] = v;
+    }
 }
 
-// column sums of `nrow` partial rows into out[N]; scratch = RS_SPLIT * N floats
-int launch_rows_sum(const float* part, int64_t nrow, int N, int64_t stride, float* scratch, float* out, hipStream_t st) {
+// column sums of `nrow` partial rows into out[N]; scratch = RS_SPLIT * N floats.  out_hi: the columns from n_lo on go there instead
+// (one pair of launches for two vectors that sit side by side in the partial rows)
+int launch_rows_sum(const float* part, int64_t nrow, int N, int64_t stride, float* scratch, float* out, hipStream_t st,
+                    float* out_hi = nullptr, int n_lo = 0) {
     const unsigned gx = (unsigned)((N + 63) / 64);
     if (nrow <= 4 * RS_SPLIT) {
-        hipLaunchKernelGGL(rows_sum, dim3(gx, 1), dim3(256), 0, st, part, nrow, N, stride, nrow, out);
+        hipLaunchKernelGGL(rows_sum, dim3(gx, 1), dim3(256), 0, st, part, nrow, N, stride, nrow, out, out_hi, n_lo);
         OV_LAUNCH_CHECK();
         return OV_OK;
     }
     const int64_t per = (nrow + RS_SPLIT - 1) / RS_SPLIT;
     const int64_t nsplit = (nrow + per - 1) / per;
-    hipLaunchKernelGGL(rows_sum, dim3(gx, (unsigned)nsplit), dim3(256), 0, st, part, nrow, N, stride, per, scratch);
+    hipLaunchKernelGGL(rows_sum, dim3(gx, (unsigned)nsplit), dim3(256), 0, st, part, nrow, N, stride, per, scratch, (float*)nullptr, 0);
     OV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(rows_sum, dim3(gx, 1), dim3(256), 0, st, (const float*)scratch, nsplit, N, (int64_t)N, nsplit, out);
+    hipLaunchKernelGGL(rows_sum, dim3(gx, 1), dim3(256), 0, st, (const float*)scratch, nsplit, N, (int64_t)N, nsplit, out, out_hi, n_lo);
     OV_LAUNCH_CHECK();
     return OV_OK;
 }
@@ -468,7 +475,7 @@ inline int64_t lnb_blocks(int64_t rows) { const int64_t b = (rows + 3) / 4; retu
 
 extern "C" size_t ov_layernorm_backward_workspace_bytes(int64_t rows, int D) {
     if (rows <= 0 || D <= 0) return 0;
-    return (size_t)lnb_blocks(rows) * 4 * 2 * D * sizeof(float) + (size_t)RS_SPLIT * D * sizeof(float);
+    return (size_t)lnb_blocks(rows) * 4 * 2 * D * sizeof(float) + (size_t)RS_SPLIT * 2 * D * sizeof(float);
 }
 
 extern "C" int ov_layernorm_backward(const ov_bf16* x, int64_t ldx, const float* gamma, const ov_bf16* dy, int64_t lddy,
@@ -492,9 +499,8 @@ extern "C" int ov_layernorm_backward(const ov_bf16* x, int64_t ldx, const float*
     OV_LAUNCH_CHECK();
     // part[w][0][:] = dgamma partial, part[w][1][:] = dbeta partial of wave w: two strided column sums
     float* scratch = part + (size_t)blocks * 4 * 2 * D;
-    int rc;
-    if ((rc = launch_rows_sum(part, blocks * 4, D, (int64_t)2 * D, scratch, dgamma, st)) != OV_OK) return rc;
-    return launch_rows_sum(part + D, blocks * 4, D, (int64_t)2 * D, scratch, dbeta, st);
+    // part[w] = [dgamma partial | dbeta partial]: both column sums from one pair of launches (the same additions in the same order)
+    return launch_rows_sum(part, blocks * 4, 2 * D, (int64_t)2 * D, scratch, dgamma, st, dbeta, D);
 }
 
 extern "C" int ov_gelu_backward(const ov_bf16* a, int64_t lda, const ov_bf16* dh, int64_t lddh, ov_bf16* da, int64_t ldda, ov_bf16* h_out,
