@@ -45,6 +45,7 @@ struct GemmArgs {
     float* psum;                         // gemm_bf16_pp_tn: [gridDim.y][M] column sums of P over the split's rows (NULL = off)
 };
 
+template <int V> struct IntC { static constexpr int value = V; };
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -213,6 +214,123 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_256x256(const GemmArgs 
     }
 
     gemm_epilogue<EPI>(g, acc, smem, m0, n0, wave, lane);
+}
+
+// =====================================================================================================
+// Experimental (OVHIP_GEMM_VARIANT=3): FOUR waves per workgroup, one per SIMD, each owning a 128 x 128 quarter of the 256 x 256 tile
+// (8 x 8 accumulator fragments = 256 registers; launch bound 1 wave per SIMD = 512 registers).  Per K-tile a wave reads 32
+// fragments for 128 MFMAs where the ping-pong kernels read 24 for 64: a third less LDS traffic per flop, no partner wave whose
+// load segment interferes with the MFMA stream, ONE barrier per K-tile.  The wave software-pipelines its own operands: while the
+// 64 MFMAs of k-half 0 run it issues the 16 LDS-DMAs of the next K-tile (whole 128-byte lines, 8 rows per instruction: v1's LDS
+// image) and the 16 fragment reads of k-half 1; half-way through k-half 1 it waits for its DMAs, meets the other waves at the
+// barrier and reads the next K-tile's k-half 0 fragments under the remaining MFMAs.  Non-persistent prototype with the shared
+// epilogue (each wave plays two of the epilogue's "waves"); measures what the main loop is worth before anything is built on it.
+template <int EPI>
+__global__ __launch_bounds__(256, 1) void gemm_bf16_w4(const GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwg = g.tiles_m * g.tiles_n;
+    const int bid = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    const int tm = wgid / g.tiles_n, tn = wgid - tm * g.tiles_n;
+    const int64_t m0 = (int64_t)tm * BM;
+    const int n0 = tn * BN;
+
+    // staging: instruction j (0..7) of this wave fills rows (4 j + wave) * 8 + (lane >> 3), stored chunk lane & 7 = logical chunk
+    // (lane & 7) ^ (row & 7) (v1's image: 128-byte rows, conflict-free for the 16x16x32 operand reads)
+    const ov_bf16* asrc[8];
+    const ov_bf16* wsrc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int row = (4 * j + wave) * 8 + (lane >> 3);
+        const int ch = (lane & 7) ^ (row & 7);
+        int64_t ar = m0 + row;
+        ar = ar < g.M ? ar : g.M - 1;
+        int wr = n0 + row;
+        wr = wr < g.N ? wr : g.N - 1;
+        asrc[j] = g.A + ar * g.lda + ch * 8;
+        wsrc[j] = g.W + (int64_t)wr * g.ldw + ch * 8;
+    }
+    char* const sdst = smem + wave * 1024;
+    auto dma = [&](int buf, int q, int k0) {      // q 0..7: A rows block q; 8..15: W
+        char* d = sdst + buf * STAGE_BYTES + (q >> 3) * TILE_BYTES + (q & 7) * 4096;
+        const ov_bf16* src = (q < 8 ? asrc[q & 7] : wsrc[q & 7]) + k0;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)d, 16, 0, 0);
+    };
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int a_off = (wm * 128 + fr) * 128;
+    const int w_off = TILE_BYTES + (wn * 128 + fr) * 128;
+    const int sw0 = (fq ^ (fr & 7)) << 4, sw1 = ((4 + fq) ^ (fr & 7)) << 4;
+    auto frag = [&](const char* st, int f, int kh) {      // f 0..7: A fragment i = f; 8..15: W fragment j = f - 8
+        return *(const bf16x8_t*)(st + (f < 8 ? a_off : w_off) + (f & 7) * 2048 + (kh ? sw1 : sw0));
+    };
+
+    f32x4_t acc0[8][4], acc1[8][4];               // columns j 0-3 / 4-7 of the wave's 8 x 8 fragment grid
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc0[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc1[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+
+    const int nt = g.K / BK;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) dma(0, q, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    bf16x8_t cur[16], nxt[16];
+#pragma unroll
+    for (int f = 0; f < 16; ++f) cur[f] = frag(smem, f, 0);
+
+    // accumulators pinned to AGPRs ("+a"): left to itself hipcc keeps them in VGPRs and parks the FRAGMENTS in AGPRs, which MFMA
+    // operands cannot come from -- 170 v_accvgpr moves and their s_nops per K-tile
+    auto mma = [&](f32x4_t& c, const bf16x8_t& wfrag, const bf16x8_t& afrag) {
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(wfrag), "v"(afrag));
+    };
+    auto ktile = [&](int t, auto morec) {
+        constexpr bool MORE = decltype(morec)::value;
+        const char* st = smem + (t & 1) * STAGE_BYTES;
+        // ---- k-half 0: 64 MFMAs; under them the next K-tile's 16 DMAs and this K-tile's k-half 1 fragments
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            nxt[q] = frag(st, q, 1);
+            if (MORE && q < 8) { dma((t + 1) & 1, 2 * q, (t + 1) * BK); dma((t + 1) & 1, 2 * q + 1, (t + 1) * BK); }   // all out in the first half
+            const int i = q >> 1;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                if (q & 1) mma(acc1[i][jj], cur[12 + jj], cur[i]);
+                else mma(acc0[i][jj], cur[8 + jj], cur[i]);
+            }
+        }
+        // ---- k-half 1: 64 MFMAs; half-way the DMAs have landed for everybody, then the next K-tile's k-half 0 fragments
+        const char* sn = smem + ((t + 1) & 1) * STAGE_BYTES;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            if (MORE && q == 10) {                                 // as late as the fragment reads below allow: the DMAs get >= 1.1 k cycles
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            if (MORE && q >= 10) {                                 // 16 reads over six groups: 3 3 3 3 2 2
+                const int f0 = q < 14 ? 3 * (q - 10) : 12 + 2 * (q - 14), nf = q < 14 ? 3 : 2;
+#pragma unroll
+                for (int f = 0; f < 3; ++f)
+                    if (f < nf) cur[f0 + f] = frag(sn, f0 + f, 0);
+            }
+            const int i = q >> 1;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                if (q & 1) mma(acc1[i][jj], nxt[12 + jj], nxt[i]);
+                else mma(acc0[i][jj], nxt[8 + jj], nxt[i]);
+            }
+        }
+    };
+    for (int t = 0; t + 1 < nt; ++t) ktile(t, IntC<1>{});
+    ktile(nt - 1, IntC<0>{});
+    // each wave plays the epilogue's waves (wm, 2 wn) and (wm, 2 wn + 1): same images, same arithmetic
+    gemm_epilogue<EPI>(g, acc0, smem, m0, n0, wm * 4 + wn * 2, lane);
+    gemm_epilogue<EPI>(g, acc1, smem, m0, n0, wm * 4 + wn * 2 + 1, lane);
 }
 
 // =====================================================================================================
@@ -832,7 +950,6 @@ __device__ __forceinline__ void epilogue_stream_lds(const GemmArgs& g, f32x4_t (
     if (wst != nullptr && lane == 0) wst[5] = __builtin_amdgcn_s_memtime();
 }
 
-template <int V> struct IntC { static constexpr int value = V; };
 struct TileSrc { const ov_bf16* a0; const ov_bf16* a1; const ov_bf16* w0; const ov_bf16* w1; };   // per-lane staging sources
 
 template <int EPI, bool FOLD, bool DIRECT, bool MAPPED, bool KEEP = false>
@@ -1108,11 +1225,11 @@ unsigned long long* g_stamps = nullptr;
 unsigned long long* g_wstamps = nullptr;
 int g_stamp_slots = 0;
 
-int gemm_variant() {       // 0 = persistent ping-pong (default), 1 = v1 two-stage, 2 = non-persistent ping-pong
+int gemm_variant() {       // 0 = persistent ping-pong (default), 1 = v1 two-stage, 2 = non-persistent ping-pong, 3 = four-wave prototype
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("OVHIP_GEMM_VARIANT");
-        v = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 0;
+        v = (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 0;
     }
     return v;
 }
@@ -1180,7 +1297,9 @@ int launch(GemmArgs a, hipStream_t st) {
         a.C2 = nullptr;
         var = 2;
     }
-    if (var == 1) {
+    if (var == 3) {
+        hipLaunchKernelGGL(gemm_bf16_w4<EPI>, dim3(nwg), dim3(256), 0, st, a);
+    } else if (var == 1) {
         hipLaunchKernelGGL(gemm_bf16_256x256<EPI>, dim3(nwg), dim3(NTHREADS), 0, st, a);
     } else if (var == 2) {
         hipLaunchKernelGGL(gemm_bf16_pp<EPI>, dim3(nwg), dim3(NTHREADS), 0, st, a);

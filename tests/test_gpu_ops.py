@@ -728,3 +728,35 @@ def test_gemm_tn_matches_transposed_operands(Mc, NI, NJ, chunk):
         assert err < 0.02 * (k1 - k0) ** 0.5 * 0.25 + 0.05, (z, err)
         ref2[z] = H.gemm(pt[:, k0:k1], qt[:, k0:k1], None, epi=0)
     assert torch.equal(got, ref2)
+
+
+@pytest.mark.parametrize("variant", ["1", "2", "3"])
+def test_gemm_kernel_variants_agree_bitwise_with_the_default(variant):
+    """OVHIP_GEMM_VARIANT (read once per process, so each variant runs in a child process): the simple two-stage kernel (1), the
+    non-persistent ping-pong kernel (2) and the four-wave prototype (3) accumulate the same products in the same order and share the
+    epilogue arithmetic: every epilogue's output must equal the default persistent kernel's bit for bit, on ragged shapes too."""
+    import subprocess, sys, tempfile
+    code = r"""
+import os, sys, torch
+sys.path.insert(0, os.environ["OV_ROOT"]); sys.path.insert(0, os.path.join(os.environ["OV_ROOT"], "tests"))
+import hipops as H
+g = torch.Generator().manual_seed(3)
+outs = []
+for (M, N, K) in ((2048, 1024, 256), (65792, 1024, 256), (1500, 776, 320)):
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda(); w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).cuda()
+    b = torch.randn(N, generator=g).cuda(); r = torch.randn(M, N, generator=g).to(torch.bfloat16).cuda()
+    for epi in (0, 1, 2, 3, 4):
+        outs.append(H.gemm(a, w, b, epi=epi, resid=r if epi >= 3 else None).cpu())
+torch.save(outs, sys.argv[1])
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    with tempfile.TemporaryDirectory() as d:
+        for v in ("0", variant):
+            path = os.path.join(d, f"v{v}.pt")
+            env = dict(os.environ, OVHIP_GEMM_VARIANT=v, OV_ROOT=root)
+            subprocess.run([sys.executable, "-c", code, path], check=True, env=env, timeout=600)
+            res[v] = torch.load(path)
+    assert len(res["0"]) == 15
+    for i, (x, y) in enumerate(zip(res["0"], res[variant])):
+        assert torch.equal(x, y), (variant, i)
