@@ -11,6 +11,8 @@ import threading
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libovhip.so")
+if os.environ.get("OVHIP_LIB"):          # diagnostics only: A/B builds with compile-time switches (tools/build_variant.py), same ABI
+    LIB_PATH = os.path.join(_PKG, os.environ["OVHIP_LIB"]) if os.sep not in os.environ["OVHIP_LIB"] else os.environ["OVHIP_LIB"]
 
 OV_F32, OV_BF16 = 0, 1
 EPI_BIAS, EPI_GELU_ERF, EPI_GELU_TANH, EPI_RESIDUAL = 0, 1, 2, 3

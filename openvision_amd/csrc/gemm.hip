@@ -43,6 +43,7 @@ struct GemmArgs {
     int epi_prio;                        // persistent kernel: n > 0: waves 4-7 (the arbitration losers) run epilogue passes < n at s_setprio 1
     ov_bf16* C2; int64_t ldc2;           // ov_gemm_keep: second output = the GELU epilogue's pre-activation (acc + bias), bf16
     float* psum;                         // gemm_bf16_pp_tn: [gridDim.y][M] column sums of P over the split's rows (NULL = off)
+    int exp;                             // persistent kernel: experiment bits (OVHIP_GEMM_EXP; none defined at present)
 };
 
 template <int V> struct IntC { static constexpr int value = V; };
@@ -649,6 +650,23 @@ constexpr int PRM_OFF = SMEM_BYTES;                  // two 4-KiB parameter bloc
 constexpr int IMG_OFF = PRM_OFF + 2 * 4096;          // DIRECT == false only: 8 wave-local 2-KiB transposition images (16 rows x 64 n bf16)
 constexpr int SMEM_PERSIST = IMG_OFF + 8 * 2048;     // 152 KiB of the CU's 160 (136 KiB without the images)
 
+// 16-byte output store with a compile-time cache policy: 0 = plain, 1 = sc1 (write-through; the line is not kept in the XCD's L2 --
+// MI355X_MICROARCH.md, store flavours), 2 = nt (streaming), 4 = sc0 sc1.  A tile's 128 KiB of output otherwise displace the W slice /
+// A panels the next K-tiles are about to be fetched from (32 CUs x 128 KiB = the whole 4 MiB L2 of an XCD per round of tiles).
+#ifndef OVHIP_ST_LDS
+#define OVHIP_ST_LDS 2          /* policy of the LDS-transposed (whole-line) epilogue's stores */
+#endif
+#ifndef OVHIP_ST_DIRECT
+#define OVHIP_ST_DIRECT 2       /* policy of the direct (row-per-lane, half-line) epilogue's stores */
+#endif
+template <int POLICY>
+__device__ __forceinline__ void store16(ov_bf16* dst, u32x4_t v) {
+    if (POLICY == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(dst), "v"(v) : "memory");
+    else if (POLICY == 2) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" :: "v"(dst), "v"(v) : "memory");
+    else if (POLICY == 4) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(dst), "v"(v) : "memory");
+    else *(u32x4_t*)dst = v;
+}
+
 // Epilogue of the persistent kernel.  After the MFMAs a lane (fr = lane & 15, fq = lane >> 4) holds, for each of its 8 fragment rows i
 // and 4 column blocks j, four consecutive n of ONE output row: acc[i][j][0..3] = C[i*16 + fr][j*16 + fq*4 + 0..3].  Packed to bf16
 // that is 8 bytes per (i, j).  Two v_permlane16_swap per pair of column blocks (j0, j0 + 1) exchange the 8 bytes of block j0 + 1 in
@@ -739,7 +757,7 @@ __device__ __forceinline__ void epilogue_stream(const GemmArgs& g, f32x4_t (&acc
         for (int h = 0; h < 2; ++h) {
             u32x4_t o = vo[i][h];
             if (EPI >= OV_EPI_BIAS_RESIDUAL) o = epi_combine<EPI>(o, rv[i][h]);
-            if (m < (unsigned)g.M && (h ? ncol1 : ncol0)) *(u32x4_t*)(dst + h * 32) = o;
+            if (m < (unsigned)g.M && (h ? ncol1 : ncol0)) store16<OVHIP_ST_DIRECT>(dst + h * 32, o);
         }
     };
     // vmcnt is counted by hand around the asm residual loads: `edge` tiles issue fewer than 2 stores per pass, so they
@@ -789,7 +807,7 @@ __device__ __forceinline__ void epilogue_stream(const GemmArgs& g, f32x4_t (&acc
             for (int h = 0; h < 2; ++h) {
                 const u32x2_t s0 = __builtin_amdgcn_permlane16_swap(pk2[2 * h][0], pk2[2 * h + 1][0], false, false);
                 const u32x2_t s1 = __builtin_amdgcn_permlane16_swap(pk2[2 * h][1], pk2[2 * h + 1][1], false, false);
-                if (m < (unsigned)g.M && (h ? ncol1 : ncol0)) *(u32x4_t*)(dst2 + h * 32) = u32x4_t{s0[0], s1[0], s0[1], s1[1]};
+                if (m < (unsigned)g.M && (h ? ncol1 : ncol0)) store16<OVHIP_ST_DIRECT>(dst2 + h * 32, u32x4_t{s0[0], s1[0], s0[1], s1[1]});
             }
         }
 #pragma unroll
@@ -881,12 +899,12 @@ __device__ __forceinline__ void epilogue_stream_lds(const GemmArgs& g, f32x4_t (
             if (EPI >= OV_EPI_BIAS_RESIDUAL) o = epi_combine<EPI>(o, rv[i][it]);
             const unsigned m = (unsigned)m0 + wm * 128 + i * 16 + it * 8 + er;
             if (!MAPPED) {   // no row map: the lane's row pointer of pass 0, stepped by whole rows
-                if (m < (unsigned)g.M && ncol) *(u32x4_t*)(cbase_lds + (int64_t)(i * 16 + it * 8) * g.ldc) = o;
+                if (m < (unsigned)g.M && ncol) store16<OVHIP_ST_LDS>(cbase_lds + (int64_t)(i * 16 + it * 8) * g.ldc, o);
                 continue;
             }
             if (m < (unsigned)g.M && ncol) {
                 const unsigned orow = g.out_group ? m + m / (unsigned)g.out_group + 1 : m;
-                *(u32x4_t*)(g.C + (int64_t)orow * g.ldc + n) = o;
+                store16<OVHIP_ST_LDS>(g.C + (int64_t)orow * g.ldc + n, o);
             }
         }
     };
@@ -999,19 +1017,30 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist(const GemmArgs 
     TileSrc cur, nxt;
     int64_t m0, nm0 = 0;
     int n0, nn0 = 0;
-    auto set_tile = [&](int trel, TileSrc& ts, int64_t& mm, int& nn) {
-        int tm, tn;
-        if (grouped) {
-            const int per = pc * g.ngroup;
-            const int ng = trel / per, rem = trel - ng * per;
-            const int pm = rem / g.ngroup;
-            tm = p0 + pm;
-            tn = ng * g.ngroup + (rem - pm * g.ngroup);
-        } else {
-            const int wg = xstart + trel;
-            tm = wg / g.tiles_n;
-            tn = wg - tm * g.tiles_n;
-        }
+    // The walk as a mixed-radix counter (n within group | panel | group), stepped by the workgroup's stride `nper` with carries: no
+    // integer division per tile (hipcc expands each into ~25 VALU instructions in front of the tile's first K-tile).  Plain walk =
+    // the same counter with radices (tiles_n | unbounded | -): digit 1 is then the row tile itself.
+    const int rad0 = grouped ? g.ngroup : g.tiles_n;
+    const int rad1 = grouped ? pc : 0x7fffffff;
+    int d0, d1, d2, s0, s1, s2;                       // digits of the NEXT tile to set up / of the stride
+    {
+        const int base = grouped ? li : xstart + li;
+        d0 = base % rad0;
+        const int q = base / rad0;
+        d1 = grouped ? q % rad1 : q;
+        d2 = grouped ? q / rad1 : 0;
+        s0 = nper % rad0;
+        const int qs = nper / rad0;
+        s1 = grouped ? qs % rad1 : qs;
+        s2 = grouped ? qs / rad1 : 0;
+    }
+    auto set_tile = [&](TileSrc& ts, int64_t& mm, int& nn) {      // sets up the tile the counter points at, then steps the counter
+        const int tm = p0 + d1, tn = d2 * rad0 + d0;
+        d0 += s0;
+        if (d0 >= rad0) { d0 -= rad0; ++d1; }
+        d1 += s1;
+        if (d1 >= rad1) { d1 -= rad1; ++d2; }
+        d2 += s2;
         mm = (int64_t)tm * BM;
         nn = tn * BN;
         int64_t ar0 = mm + srow, ar1 = mm + 128 + srow;
@@ -1076,7 +1105,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist(const GemmArgs 
     const int a_lane = (wm * 128 + fr) * 64 + lsw;
     const int w_lane = PIECE_BYTES + (wn * 64 + fr) * 64 + lsw;
     const int nt = g.K / BK;                                       // >= 3 (launcher)
-    set_tile(tcur, cur, m0, n0);
+    set_tile(cur, m0, n0);
 #pragma unroll
     for (int j = 0; j < 4; ++j) stage_piece(cur, 0, j);
     advance(cur);
@@ -1142,8 +1171,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist(const GemmArgs 
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[mh * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[mh * 4 + i][j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) {
+                    // a tile's first products start from a literal zero C operand: no 128 v_mov per tile to clear the accumulators
+                    if (KIND == 0 && kh == 0)
+                        acc[mh * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    else
+                        acc[mh * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[mh * 4 + i][j], 0, 0, 0);
+                }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
@@ -1154,12 +1188,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist(const GemmArgs 
         stamp(0);
         const int tnext = tcur + nper;
         has_next = tnext < xcnt;
-        if (has_next) set_tile(tnext, nxt, nm0, nn0);
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
+        if (has_next) set_tile(nxt, nm0, nn0);
         ktile(IntC<0>{});
         cb ^= STAGE_BYTES;
         stamp(4);
@@ -1264,6 +1293,12 @@ int gemm_stagger_classes() {
     return v;
 }
 
+int gemm_exp() {           // experiment bits of the persistent kernel (timing studies; 0 in production)
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("OVHIP_GEMM_EXP"); v = e ? atoi(e) : 0; }
+    return v;
+}
+
 int gemm_epi_prio() {
     static int v = -1;
     // default 4: waves 4-7 (younger, they lose every VALU / LDS arbitration against waves 0-3 and finish the epilogue 1.4 k cycles
@@ -1360,7 +1395,7 @@ extern "C" int ov_gemm(const ov_bf16* A, int64_t lda, const ov_bf16* W, int64_t 
     if (tiles_m * tiles_n > 0x7fffffffLL || M > 0x7fff0000LL) return OV_ERR_UNSUPPORTED;    // 32-bit row indices in the kernels
     GemmArgs a{A, W, bias, C, R, lda, ldw, ldc, ldr, M, N, K, (int)tiles_m, (int)tiles_n,
                out_group, resid_mod, resid_off, g_colsum, g_rowstats, g_stamps, g_stamp_slots, g_wstamps, gemm_ngroup((int)tiles_m, (int)tiles_n, K), 0, 0, 0,
-               gemm_stagger(K), gemm_stagger_classes(), gemm_epi_prio(), g_keep, g_ldkeep};
+               gemm_stagger(K), gemm_stagger_classes(), gemm_epi_prio(), g_keep, g_ldkeep, nullptr, gemm_exp()};
     hipStream_t st = (hipStream_t)stream;
     switch (epilogue) {
         case OV_EPI_BIAS: return launch<OV_EPI_BIAS>(a, st);

@@ -25,11 +25,12 @@ for name in sys.argv[1:] or list(cases):
     lib.ov_debug_gemm_stamps(None, 0); lib.ov_debug_gemm_wave_stamps(None)
     st = buf.cpu().numpy().reshape(256, slots, 8).astype(np.float64)
     ws = wbuf.cpu().numpy().reshape(256, slots, 8, 8).astype(np.float64)
-    ok = (ws[:, 1:4, :, 6] > 0).all(axis=(1, 2))
-    ws = ws[ok][:, 1:4]                               # tiles 1..3 of every workgroup that ran >= 5 tiles
+    nt_ = 3 if (ws[:, 1:4, :, 6] > 0).all(axis=(1, 2)).any() else 2      # tiles 1..3 (>= 5 tiles per workgroup) or 1..2 (4 tiles)
+    ok = (ws[:, 1:1 + nt_, :, 6] > 0).all(axis=(1, 2))
+    ws = ws[ok][:, 1:1 + nt_]
     t0 = ws[:, :, :, 0].min(axis=2, keepdims=True)    # first wave out of the main loop
     names = ["main loop end", "epilogue_stream entry", "parameters read", "pass 1 done", "pass 4 done", "last store issued", "past tile barrier"]
-    print(f"{name}: N={N} K={K} epi={epi}; cycles after the first wave left the main loop, mean over {ws.shape[0]} workgroups x 3 tiles")
+    print(f"{name}: N={N} K={K} epi={epi}; cycles after the first wave left the main loop, mean over {ws.shape[0]} workgroups x {nt_} tiles")
     for k, nm in enumerate(names):
         d = ws[:, :, :, k] - t0
         print(f"   {nm:<24} per wave 0..7: " + " ".join(f"{v:7.0f}" for v in d.mean(axis=(0, 1))) + f"   | max over waves {d.max(axis=2).mean():7.0f}")
