@@ -79,7 +79,7 @@ def dry_run_gloo(a, result_out) -> None:
     over ranks, one JSON line on rank 0).  No throughput is reported: nothing is computed."""
     import torch
     import torch.distributed as dist
-    from openvision_amd.loss import gather_features
+    from openvision_amd.loss import gather_features, record_comm
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     if world > 1:
         dist.init_process_group("gloo")
@@ -94,13 +94,18 @@ def dry_run_gloo(a, result_out) -> None:
     ok = True
     for _ in range(a.warmup):
         gather_features(li, lt, True, False, rank, world)
+    comm_log = []
+    record_comm(comm_log if world > 1 else None)
     fence()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         ai, at = gather_features(li, lt, True, False, rank, world)
         ok = ok and bool(torch.equal(ai, full_i) and torch.equal(at, full_t))
     fence()
-    dt = torch.tensor([time.perf_counter() - t0, 0.0 if ok else 1.0], dtype=torch.float64)
+    record_comm(None)
+    own_dt = time.perf_counter() - t0
+    dt = torch.tensor([own_dt, 0.0 if ok else 1.0], dtype=torch.float64)
+    comm = comm_summary(comm_log, own_dt, a.steps, li.shape[0] * 2 * e * 4, world, None)
     if world > 1:
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     if rank == 0:
@@ -108,13 +113,39 @@ def dry_run_gloo(a, result_out) -> None:
                                      "n_gpus": 0, "n_ranks_seen": dist.get_world_size() if world > 1 else 1,
                                      "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(float(dt[0]) / a.steps * 1e3, 3),
                                      "gather_rank_ordered": bool(dt[1] == 0), "scaling": "weak", "data": "synthetic",
-                                     "dry_run": True}) + "\n")
+                                     "comm": comm, "dry_run": True}) + "\n")
         result_out.flush()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if dt[1] != 0:
         raise SystemExit("gathered rows are not in rank order")
+
+
+def comm_summary(comm_log, own_dt, steps, payload_bytes, world, dev):
+    """What a first multi-GPU run needs to be diagnosed (every rank calls this: it holds two small collectives): the exchange step's
+    own time inside the timed region (one all-gather of the packed [b, 2E] fp32 embeddings per step: event pairs on the launch
+    stream, recorded by gather_features) and every rank's step time before the max over ranks.  None in a world of one."""
+    if world <= 1:
+        return None
+    import torch
+    import torch.distributed as dist
+    if comm_log and not isinstance(comm_log[0][0], float):
+        ag = [e0.elapsed_time(e1) for e0, e1 in comm_log]                 # ms; the caller has synchronised
+    else:
+        ag = [(t1 - t0) * 1e3 for t0, t1 in comm_log]
+    mine = torch.tensor([own_dt / steps * 1e3, sum(ag) / max(len(ag), 1), max(ag) if ag else 0.0], dtype=torch.float64,
+                        device=dev if dev is not None else "cpu")
+    allr = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(allr, mine)
+    rows = torch.stack(allr).cpu()
+    return {"collective": "all_gather_into_tensor(packed [b, 2E] fp32), one per step", "payload_bytes": int(payload_bytes),
+            "received_bytes_per_rank": int(payload_bytes) * world, "calls_timed": len(ag),
+            "allgather_ms": round(float(rows[:, 1].mean()), 4), "allgather_ms_max_rank": round(float(rows[:, 1].max()), 4),
+            "allgather_ms_worst_call": round(float(rows[:, 2].max()), 4),
+            "rank_ms_per_step": {"min": round(float(rows[:, 0].min()), 3), "max": round(float(rows[:, 0].max()), 3),
+                                 "per_rank": [round(float(v), 3) for v in rows[:, 0]]},
+            "note": "the all-gather time includes waiting for the slowest rank's towers (it is the step's only synchronisation point)"}
 
 
 def cpu_model() -> str:
@@ -219,7 +250,7 @@ def main():
 
     from openvision_amd import preset, synth, _lib
     from openvision_amd.model import create_model
-    from openvision_amd.loss import ClipLoss
+    from openvision_amd.loss import ClipLoss, record_comm
     lib = _lib.load()
     _lib.check(lib.ov_device_check(), "ov_device_check")
 
@@ -262,12 +293,16 @@ def main():
     # in-situ timing of the dominant kernel (the vision MLP c_fc GEMM) during the timed region
     nrec = a.steps * max(1, a.micro_batches) * cfg["vision_cfg"]["layers"] + 8
     _lib.check(lib.ov_profile_enable(1 << PROF_CLASSES["gemm_fc"], nrec), "ov_profile_enable")
+    comm_log = []
+    record_comm(comm_log if world > 1 else None)
     fence()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = step()
     fence()
     dt = time.perf_counter() - t0
+    record_comm(None)
+    comm = comm_summary(comm_log, dt, a.steps, b * mb * 2 * cfg["embed_dim"] * 4, world, dev)
     tot, cnt, rows = C.c_double(0), C.c_int(0), C.c_double(0)
     _lib.check(lib.ov_profile_read(PROF_CLASSES["gemm_fc"], C.byref(tot), C.byref(cnt), C.byref(rows)), "ov_profile_read")
     _lib.check(lib.ov_profile_enable(0, 0), "ov_profile_enable")
@@ -345,9 +380,12 @@ def main():
                                    f"M={int(rows.value / launches)} rows per launch",
                          "achieved": round(achieved, 1), "peak": peak_tf, "unit": "TFLOP/s",
                          "frac": round(achieved / peak_tf, 4), "traffic": traffic if a.precision == "bf16" else None,
+                         "traffic_source": ("profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this "
+                                            "command, NOT measured in this run") if (traffic is not None and a.precision == "bf16") else None,
                          "avg_launch_ms": round(avg_ms, 4), "launches": cnt.value,
                          "flop_per_launch": flop_per_launch},
         }
+        out["comm"] = comm
         if breakdown:
             out["breakdown"] = breakdown
         if world == 1 and a.cpu_seconds > 0:

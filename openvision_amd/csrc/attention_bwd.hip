@@ -142,7 +142,9 @@ __global__ __launch_bounds__(640) void attn_bwd_hd64(const AttnBwdArgs a) {
         }
         float lse2;
         if (SAVED) {
-            lse2 = a.lse_in[(int64_t)blockIdx.x * KC + query];   // rows past L hold row L - 1's value (never used: p = 0 there)
+            // the forward writes entries [0, L) only (padded query lanes re-store row L - 1 at index L - 1): entries [L, KC) are
+            // whatever the recycled buffer held, possibly NaN / Inf -- never read them (p = 0 is selected for q >= L further down)
+            lse2 = query < L ? a.lse_in[(int64_t)blockIdx.x * KC + query] : 0.f;
         } else {
             const float mo = swap_halves(m), lo = swap_halves(l);
             const float mn = fmaxf(m, mo);                       // finite: key 0 is always valid for one of the halves

@@ -23,6 +23,17 @@ from . import _lib
 from ._lib import ptr, stream_ptr, check
 
 
+_COMM_LOG = None      # diagnostics (bench.py --gpus N): a list that gather_features appends one (start, end) pair per collective to
+
+
+def record_comm(log) -> None:
+    """Diagnostics: pass a list to have every all-gather of gather_features bracketed by a pair of timing marks appended to it --
+    ``torch.cuda.Event``s recorded on the current stream for device tensors (the collective is stream-ordered: the current stream waits
+    for it), ``time.perf_counter()`` floats on the CPU (gloo rehearsal).  ``None`` turns it off.  Nothing is synchronised here."""
+    global _COMM_LOG
+    _COMM_LOG = log
+
+
 def gather_features(image_features: torch.Tensor, text_features: torch.Tensor, local_loss: bool = False,
                     gather_with_grad: bool = False, rank: int = 0, world_size: int = 1, use_horovod: bool = False,
                     group=None, force: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -37,7 +48,19 @@ def gather_features(image_features: torch.Tensor, text_features: torch.Tensor, l
     b, e = image_features.shape
     packed = torch.cat([image_features.detach().float(), text_features.detach().float()], dim=1).contiguous()
     out = torch.empty(world_size * b, 2 * e, dtype=torch.float32, device=packed.device)
-    dist.all_gather_into_tensor(out, packed, group=group)
+    if _COMM_LOG is None:
+        dist.all_gather_into_tensor(out, packed, group=group)
+    elif packed.is_cuda:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        dist.all_gather_into_tensor(out, packed, group=group)
+        e1.record()
+        _COMM_LOG.append((e0, e1))
+    else:
+        import time
+        t0 = time.perf_counter()
+        dist.all_gather_into_tensor(out, packed, group=group)
+        _COMM_LOG.append((t0, time.perf_counter()))
     return out[:, :e].contiguous(), out[:, e:].contiguous()
 
 

@@ -58,11 +58,13 @@ class _Workspace:
 
     def __init__(self):
         self.buf: Optional[torch.Tensor] = None
+        self.gen = 0            # bumped on every reallocation: captured hipGraphs hold the OLD buffer's address (_GraphCache)
 
     def get(self, nbytes: int, device) -> torch.Tensor:
         if self.buf is None or self.buf.device != device or self.buf.numel() < nbytes:
             self.buf = None
             self.buf = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=device)
+            self.gen += 1
         return self.buf
 
 
@@ -96,26 +98,30 @@ class _GraphCache:
     """hipGraph replay of a launch-bound encode call (batch-1 zero-shot path: ~170 kernel launches per image whose host-side
     launch cost exceeds their device time).  The launch sequence is captured ONCE per (shape, dtype, flags) on a capture stream
     (every kernel of libovhip goes to the current torch stream, so torch.cuda.graph records them as graph kernel nodes), then
-    replayed: copy the input into the captured call's static input, one hipGraphLaunch, clone the static output.  Weights are
-    baked in as pointers: a parameter change (pack epoch / _version) drops the graphs."""
+    replayed: copy the input into the captured call's static input, one hipGraphLaunch, clone the static output.  Weights AND the
+    grow-only workspaces are baked in as pointers: `sig_fn()` covers both (pack epoch, parameter versions, workspace generations);
+    when it changes -- a parameter update, or a larger call (graphed or not) that made a workspace reallocate, after which the
+    old buffer may belong to somebody else -- every graph is dropped and re-captured on next use."""
 
     def __init__(self):
         self.graphs = {}
         self.sig = None
 
-    def run(self, key, weights_sig, x: torch.Tensor, fn):
-        if self.sig != weights_sig:
+    def run(self, key, sig_fn, x: torch.Tensor, fn):
+        if self.sig != sig_fn():
             self.graphs.clear()
-            self.sig = weights_sig
         ent = self.graphs.get(key)
         if ent is None:
             static_in = x.clone()
             fn(static_in)                                   # warm-up outside capture: packs weights, sizes workspaces, sets attributes
             torch.cuda.current_stream(x.device).synchronize()
+            if self.sig != sig_fn():                        # the warm-up itself grew a workspace: the other graphs hold stale pointers
+                self.graphs.clear()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 static_out = fn(static_in)
             ent = self.graphs[key] = (g, static_in, static_out)
+            self.sig = sig_fn()
         g, static_in, static_out = ent
         static_in.copy_(x)
         g.replay()
@@ -697,7 +703,8 @@ class CLIP(nn.Module):
         self.graph_max_batch = int(max_batch)
 
     def _weights_sig(self):
-        return (_PACK_EPOCH[0],) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        ws = (self._ws, self.visual._ws, self.visual.transformer._ws, self.transformer._ws)
+        return (_PACK_EPOCH[0],) + tuple(w.gen for w in ws) + tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def encode_image(self, image: torch.Tensor, normalize: bool = False) -> torch.Tensor:
         """model.py:265-267.  Returns fp32 [B, embed_dim]."""
@@ -706,7 +713,7 @@ class CLIP(nn.Module):
             x = image.detach()
             x = x.contiguous() if x.dtype in (torch.float32, torch.bfloat16) else x.float().contiguous()
             return self._graphs.run(("img", tuple(x.shape), x.dtype, bool(normalize), self.visual.transformer._cache.precision),
-                                    self._weights_sig(), x, lambda t: self.visual._encode(t, normalize))
+                                    self._weights_sig, x, lambda t: self.visual._encode(t, normalize))
         return self.visual._encode(image, normalize)
 
     def encode_text(self, text: torch.Tensor, normalize: bool = False, _graphed: bool = False) -> torch.Tensor:
@@ -716,7 +723,7 @@ class CLIP(nn.Module):
             raise ValueError(f"expected tokens [B,{self.context_length}], got {tuple(text.shape)}")
         if 0 < text.shape[0] <= self.graph_max_batch and not torch.cuda.is_current_stream_capturing() and not _graphed:
             t = text.detach().to(torch.int64).contiguous()
-            return self._graphs.run(("txt", tuple(t.shape), bool(normalize), self.transformer._cache.precision), self._weights_sig(),
+            return self._graphs.run(("txt", tuple(t.shape), bool(normalize), self.transformer._cache.precision), self._weights_sig,
                                     t, lambda z: self.encode_text(z, normalize, _graphed=True))
         lib = _lib.load()
         head, _keep = self._text_head()

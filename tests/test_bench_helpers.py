@@ -48,6 +48,12 @@ def test_bench_launches_its_own_ranks_gloo_dry_run():
     assert len(lines) == 1, p.stdout
     out = json.loads(lines[0])
     assert out["n_ranks_seen"] == 2 and out["gather_rank_ordered"] is True and out["dry_run"] is True and out["steps"] == 3
+    # what the first N > 1 run on hardware is diagnosed with: the exchange step's own time and every rank's step time
+    comm = out["comm"]
+    assert comm["calls_timed"] == 3 and comm["payload_bytes"] == 8 * 2 * 16 * 4 and comm["received_bytes_per_rank"] == 2 * comm["payload_bytes"]
+    assert 0 < comm["allgather_ms"] <= comm["allgather_ms_max_rank"] <= comm["allgather_ms_worst_call"] * 1.0001
+    rk = comm["rank_ms_per_step"]
+    assert len(rk["per_rank"]) == 2 and rk["min"] == min(rk["per_rank"]) and rk["max"] == max(rk["per_rank"]) and rk["min"] > 0
 
 
 def test_bench_launcher_propagates_rank_failure():

@@ -910,6 +910,33 @@ def test_hipgraph_replay_of_small_batch_encode_is_bitwise(tiny):
             tiny.visual.ln_post.bias.sub_(0.25)
 
 
+def test_hipgraph_survives_workspace_growth(tiny):
+    """A captured graph bakes in the addresses of the grow-only workspaces; a later, larger call (graphed or not) reallocates them and
+    the old buffer goes back to the allocator.  The graph cache carries the workspaces' generations in its signature: capture B = 1,
+    run B = 8 (graphed) and B = 64 (plain), let somebody else take the freed memory, replay B = 1 -- bit for bit the plain result."""
+    import gc
+    img = synth.make_images(64, 160, seed=91).to(DEV)
+    want1 = tiny.encode_image(img[0:1], normalize=True)
+    want8 = tiny.encode_image(img[0:8], normalize=True)
+    for m in (tiny, tiny.visual, tiny.visual.transformer, tiny.transformer):       # start from cold workspaces: B = 1 sizes them
+        m._ws.buf = None
+    gc.collect(); torch.cuda.empty_cache()
+    tiny.use_graphs(8)
+    try:
+        assert torch.equal(tiny.encode_image(img[0:1], normalize=True), want1)
+        gens = tiny._weights_sig()[1:5]
+        assert torch.equal(tiny.encode_image(img[0:8], normalize=True), want8)          # a second graph; its warm-up grows the workspaces
+        big = tiny.encode_image(img, normalize=True)                                    # above graph_max_batch: plain launches, grows again
+        assert tiny._weights_sig()[1:5] != gens
+        squatters = [torch.full((1 << 20,), float("nan"), device=DEV) for _ in range(8)]    # whoever gets the freed workspace memory
+        assert torch.equal(tiny.encode_image(img[0:1], normalize=True), want1)
+        assert torch.equal(tiny.encode_image(img[0:8], normalize=True), want8)
+        assert all(bool(torch.isnan(t).all()) for t in squatters)                       # and nobody wrote through a stale pointer
+        assert torch.equal(big[0:8], want8)
+    finally:
+        tiny.use_graphs(0)
+
+
 def test_fused_adamw_matches_the_optax_restatement(tiny):
     """training.FusedAdamW (ov_adamw_step / ov_sumsq) over three steps with clipping and a 1/world_size gradient scale against
     oracle/optim_ref.py (numpy restatement of the reference trainer's optax chain, build_optax.py:272-278: parity unpinned vs optax
