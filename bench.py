@@ -45,7 +45,8 @@ def parse():
     ap.add_argument("--micro-batches", type=int, default=1,
                     help="encode this many micro-batches of --batch pairs per step, one InfoNCE over all of them "
                          "(config #5: 16 x 256 per GPU = 32k pairs on 8 GPUs)")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp8"], help="GEMM operand precision of the block stacks")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp8", "fp8-mixed"], help="GEMM operand precision of the block stacks")
+    ap.add_argument("--fp8-mask", type=int, default=-1, help="with an fp8 precision: explicit OV_FP8_* bit set (1 QKV, 2 out_proj, 4 c_fc, 8 c_proj)")
     ap.add_argument("--dry-run-gloo", action="store_true",
                     help="CPU rehearsal of the multi-rank plumbing (launcher, rendezvous, rank-ordered all-gather, barrier-fenced "
                          "timing, max over ranks) on the gloo backend: runs no kernel and reports no throughput")
@@ -258,7 +259,7 @@ def main():
     sd = synth.make_state_dict(cfg, seed=0)
     model = create_model(cfg, device=dev, state_dict=sd)
     if a.precision != "bf16":
-        model.set_precision(a.precision)
+        model.set_precision(a.precision, a.fp8_mask if a.fp8_mask >= 0 else None)
     loss_fn = ClipLoss(local_loss=True, rank=rank, world_size=world)
     b = a.batch
     S = cfg["vision_cfg"]["image_size"]
@@ -287,7 +288,7 @@ def main():
 
     for _ in range(a.warmup):
         loss = step()
-    if a.precision == "fp8" and a.warmup > 0 and os.environ.get("OVHIP_FP8_DYNAMIC", "0") != "1":
+    if a.precision != "bf16" and a.warmup > 0 and os.environ.get("OVHIP_FP8_DYNAMIC", "0") != "1":
         model.freeze_fp8_scales()              # static scales of the MLP hidden, calibrated on the warm-up steps
         loss = step()
     # in-situ timing of the dominant kernel (the vision MLP c_fc GEMM) during the timed region
@@ -358,7 +359,10 @@ def main():
                     traffic = tj.get("gemm_fc_bytes_per_launch")
             except Exception:
                 traffic = None
-        peak_tf = PEAK_BF16_TFLOPS if a.precision == "bf16" else PEAK_FP8_TFLOPS
+        from openvision_amd.model import fp8_mixed_mask
+        eff_mask = 0 if a.precision == "bf16" else (a.fp8_mask if a.fp8_mask >= 0 else (15 if a.precision == "fp8" else fp8_mixed_mask(1)[0]))
+        fc_fp8 = bool(eff_mask & 4)                      # the roofline kernel (vision c_fc) runs on the fp8 MFMA
+        peak_tf = PEAK_FP8_TFLOPS if fc_fp8 else PEAK_BF16_TFLOPS
         out = {
             "metric": "images/sec (node) ViT-L/14@224 fwd+InfoNCE" if a.model == "vit-large-patch14-224"
                       else f"images/sec (node) {a.model} fwd+InfoNCE",
@@ -369,12 +373,13 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.precision, "data": "synthetic",
             "config": {"workload": f"{a.model}: image tower + text tower (T={T}) + InfoNCE, per-GPU batch {b}, "
-                                   f"formula weights, {'bf16' if a.precision == 'bf16' else 'fp8 e4m3 (MX-scaled)'} MFMA / fp32 accumulate",
+                                   f"formula weights, {'bf16' if a.precision == 'bf16' else 'fp8 e4m3 (MX-scaled) on GEMMs mask ' + str(eff_mask) + ' (1 QKV 2 out 4 c_fc 8 c_proj), bf16 elsewhere;'} MFMA / fp32 accumulate",
+                       "fp8_mask": eff_mask,
                        "global_batch": world * b * mb, "micro_batches": mb, "parallelism": f"dp{world}",
                        "gflop_per_pair": round(flops["pair"] / 1e9, 2),
                        "model_tflops_per_gpu": round(flops["pair"] * b * mb * a.steps / dt / 1e12, 1)},
             "loss": round(loss_val, 5),
-            "roofline": {"bound": "mfma", "kernel": (f"gemm_bf16_persist<1, true, true, false, false> (EPI erf-GELU, LN fold, direct stores)" if a.precision == "bf16"
+            "roofline": {"bound": "mfma", "kernel": (f"gemm_bf16_persist<1, true, true, false, false> (EPI erf-GELU, LN fold, direct stores)" if not fc_fp8
                                                      else "gemm_fp8_persist<1> (dequantise + bias + erf-GELU)")
                                    + f" = vision mlp.c_fc, N={int(Dv * cfg['vision_cfg']['mlp_ratio'])} K={Dv}, "
                                    f"M={int(rows.value / launches)} rows per launch",

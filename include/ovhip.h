@@ -372,6 +372,17 @@ int       ov_tower_set_block_fp8(ov_tower* t, int layer, const ov_block_fp8* q);
  * write e4m3 directly with the scale 2 * amax / 448 and the consumers (c_proj, out_proj) read it with that scalar scale; 3: as 2
  * but FROZEN: the recorded maxima are never rolled into the scales (bitwise repeatable, batch-composition invariant results). */
 int       ov_tower_set_fp8_hidden_scale(ov_tower* t, float* amax, int mode);
+/* Mixed precision of the fp8 path: mask[layer] (HOST array of n == layers bytes, copied) says which of the block's four GEMMs take e4m3
+ * operands; the others run exactly as in the bf16 path (LN fold included).  NULL restores OV_FP8_ALL for every layer.  The c_fc ->
+ * c_proj hand-over stays in e4m3 only where both are in the mask; a lone fp8 c_proj / out_proj re-quantises its bf16 input row by
+ * row (or, out_proj with mode >= 2 and head_dim 64, reads the attention kernel's e4m3 output).  Reference: none (the reference has no
+ * fp8 mode); shape source scripts/project/openvision/train.sh:18 (BASELINE.json config #5). */
+#define OV_FP8_QKV 1
+#define OV_FP8_OUT 2
+#define OV_FP8_FC 4
+#define OV_FP8_PROJ 8
+#define OV_FP8_ALL 15
+int       ov_tower_set_fp8_mask(ov_tower* t, const unsigned char* mask, int n);
 size_t    ov_tower_workspace_bytes(const ov_tower* t, int B, int L);
 /* x[B*L, D] bf16 is updated in place through all `layers` blocks. */
 int       ov_tower_forward(const ov_tower* t, ov_bf16* x, int B, int L, void* workspace,

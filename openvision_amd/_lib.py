@@ -73,6 +73,7 @@ SIGNATURES = {
     "ov_gemm_fp8_static": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
                                    c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
     "ov_tower_set_fp8_hidden_scale": (c_int, [c_void_p, c_void_p, c_int]),
+    "ov_tower_set_fp8_mask": (c_int, [c_void_p, c_void_p, c_int]),
     "ov_layernorm_quant_fp8": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_float,
                                        c_void_p]),
     "ov_gemm_ln": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int,

@@ -35,6 +35,7 @@ struct ov_tower {
     unsigned char* set8;
     float* h_amax;                // fp8 path: [4 * layers]: scales' maxima (hidden | attention out) and the running ones (device, borrowed)
     int h_mode;
+    unsigned char* mask8;         // fp8 path: per layer, which of the four GEMMs take e4m3 operands (OV_FP8_QKV | _OUT | _FC | _PROJ)
 };
 
 namespace {
@@ -190,7 +191,9 @@ extern "C" ov_tower* ov_tower_create(const ov_tower_cfg* cfg) {
     t->set = new (std::nothrow) unsigned char[cfg->layers]();
     t->fp8 = new (std::nothrow) ov_block_fp8[cfg->layers]();
     t->set8 = new (std::nothrow) unsigned char[cfg->layers]();
-    if (!t->blocks || !t->set || !t->fp8 || !t->set8) { ov_tower_destroy(t); return nullptr; }
+    t->mask8 = new (std::nothrow) unsigned char[cfg->layers];
+    if (!t->blocks || !t->set || !t->fp8 || !t->set8 || !t->mask8) { ov_tower_destroy(t); return nullptr; }
+    for (int i = 0; i < cfg->layers; ++i) t->mask8[i] = OV_FP8_ALL;
     return t;
 }
 
@@ -204,6 +207,7 @@ extern "C" void ov_tower_destroy(ov_tower* t) {
     delete[] t->blocks;
     delete[] t->set;
     delete[] t->fp8;
+    delete[] t->mask8;
     delete[] t->set8;
     delete t;
 }
@@ -246,6 +250,16 @@ extern "C" int ov_tower_set_fp8_hidden_scale(ov_tower* t, float* h_amax, int mod
     if (!t || mode < 0 || mode > 3 || (mode > 0 && !h_amax)) return OV_ERR_INVALID;
     t->h_amax = h_amax;
     t->h_mode = mode;
+    return OV_OK;
+}
+
+extern "C" int ov_tower_set_fp8_mask(ov_tower* t, const unsigned char* mask, int n) {
+    if (!t || (mask && n != t->cfg.layers)) return OV_ERR_INVALID;
+    for (int i = 0; i < t->cfg.layers; ++i) {
+        const unsigned char m = mask ? mask[i] : (unsigned char)OV_FP8_ALL;
+        if (m & ~OV_FP8_ALL) return OV_ERR_INVALID;
+        t->mask8[i] = m;
+    }
     return OV_OK;
 }
 
@@ -332,17 +346,22 @@ int tail_images(int B, int L) {
 }  // namespace
 
 namespace {
-// The same block with fp8 (e4m3) GEMM operands (BASELINE.json config #5): LN -> row quantisation fused, attention in bf16,
-// the attention output and the MLP hidden re-quantised row by row in front of out-proj / c_proj.
-int run_block_fp8(const ov_tower_cfg& c, const ov_block_weights& w, const ov_block_fp8& q, ov_bf16* x, ov_bf16* h, ov_bf16* big,
-                  unsigned char* q8, float* qs, float* h_amax, float* a_amax, float* h_next, float* a_next, int h_mode, int B, int L,
-                  ov_stream_t stream, bool prof) {
+// The same block with fp8 (e4m3) operands on the GEMMs `mask` names (BASELINE.json config #5; OV_FP8_ALL = all four): in front of an
+// fp8 QKV / c_fc the LayerNorm is fused with the row quantisation; in front of an fp8 out_proj / c_proj the attention output / MLP
+// hidden is written as e4m3 by its producer where that producer has a static scale (h_mode >= 2: attention epilogue for head_dim 64,
+// an fp8 c_fc's epilogue) and re-quantised row by row otherwise.  A GEMM outside the mask runs exactly as in run_block (LN fold
+// included), so mask 0 is the bf16 block.
+int run_block_fp8(const ov_tower_cfg& c, const ov_block_weights& w, const ov_block_fp8& q, int mask, ov_bf16* x, ov_bf16* h, ov_bf16* big,
+                  float* stats, unsigned char* q8, float* qs, float* h_amax, float* a_amax, float* h_next, float* a_next, int h_mode, int B,
+                  int L, ov_stream_t stream, bool prof) {
     const int D = c.width, H = c.heads, hd = D / H, F = c.mlp_pad;
     const int64_t M = (int64_t)B * L;
     const int ldb = 3 * D > F ? 3 * D : F;
     const float scale = 1.0f / sqrtf((float)hd);
     const int gelu = c.gelu_tanh ? OV_EPI_BIAS_GELU_TANH : OV_EPI_BIAS_GELU_ERF;
     const int fc_cls = c.gelu_tanh ? OV_PROF_GEMM_FC_TANH : OV_PROF_GEMM_FC;
+    const bool fold = w.qkv_colsum != nullptr && w.fc_colsum != nullptr;
+    const bool f_qkv = mask & OV_FP8_QKV, f_out = mask & OV_FP8_OUT, f_fc = mask & OV_FP8_FC, f_proj = mask & OV_FP8_PROJ;
     int rc;
 #define OV_STEP(cls, call)                                           \
     do {                                                             \
@@ -350,29 +369,55 @@ int run_block_fp8(const ov_tower_cfg& c, const ov_block_weights& w, const ov_blo
         else rc = (call);                                            \
         if (rc) return rc;                                           \
     } while (0)
-    OV_STEP(OV_PROF_LN, ov_layernorm_quant_fp8(x, D, w.ln1_w, w.ln1_b, q8, D, qs, M, D, c.ln_eps, stream));
-    OV_STEP(OV_PROF_GEMM_QKV, ov_gemm_fp8(q8, D, q.qkv_w8, D, qs, q.qkv_s, q.qkv_b, big, ldb, M, 3 * D, D, OV_EPI_BIAS, nullptr, 0, stream));
-    if (h_mode >= 2 && hd == 64) {
+    // ---- attention half ----
+    if (f_qkv) {
+        OV_STEP(OV_PROF_LN, ov_layernorm_quant_fp8(x, D, w.ln1_w, w.ln1_b, q8, D, qs, M, D, c.ln_eps, stream));
+        OV_STEP(OV_PROF_GEMM_QKV, ov_gemm_fp8(q8, D, q.qkv_w8, D, qs, q.qkv_s, q.qkv_b, big, ldb, M, 3 * D, D, OV_EPI_BIAS, nullptr, 0, stream));
+    } else if (fold) {
+        OV_STEP(OV_PROF_LN, ov_rowstats(x, D, stats, M, D, c.ln_eps, stream));
+        OV_STEP(OV_PROF_GEMM_QKV, ov_gemm_ln(x, D, w.qkv_w, D, w.qkv_b, w.qkv_colsum, stats, big, ldb, M, 3 * D, D, OV_EPI_BIAS, stream));
+    } else {
+        OV_STEP(OV_PROF_LN, ov_layernorm(x, OV_BF16, D, w.ln1_w, w.ln1_b, h, OV_BF16, D, M, D, c.ln_eps, stream));
+        OV_STEP(OV_PROF_GEMM_QKV, ov_gemm(h, D, w.qkv_w, D, w.qkv_b, big, ldb, M, 3 * D, D, OV_EPI_BIAS, nullptr, 0, 0, 0, 0, stream));
+    }
+    if (f_out && h_mode >= 2 && hd == 64) {
         // static scale: the attention epilogue writes e4m3 itself (into the fp8 activation buffer, free at this point)
         OV_STEP(OV_PROF_ATTN, ov_attention_fp8out(big, ldb, q8, D, B, L, H, hd, scale, a_amax, a_next, stream));
         OV_STEP(OV_PROF_GEMM_OUT, ov_gemm_fp8_static(q8, D, q.out_w8, D, nullptr, a_amax, q.out_s, w.out_b, x, D, nullptr, nullptr, M, D, D,
                                                      OV_EPI_BIAS_RESIDUAL, x, D, stream));
     } else {
         OV_STEP(OV_PROF_ATTN, ov_attention(big, ldb, h, D, B, L, H, hd, scale, stream));
-        OV_STEP(OV_PROF_LN, ov_quant_rows_fp8(h, D, q8, D, qs, M, D, h_mode == 1 ? a_amax : nullptr, stream));
-        OV_STEP(OV_PROF_GEMM_OUT, ov_gemm_fp8(q8, D, q.out_w8, D, qs, q.out_s, w.out_b, x, D, M, D, D, OV_EPI_BIAS_RESIDUAL, x, D, stream));
+        if (f_out) {
+            OV_STEP(OV_PROF_LN, ov_quant_rows_fp8(h, D, q8, D, qs, M, D, h_mode == 1 ? a_amax : nullptr, stream));
+            OV_STEP(OV_PROF_GEMM_OUT, ov_gemm_fp8(q8, D, q.out_w8, D, qs, q.out_s, w.out_b, x, D, M, D, D, OV_EPI_BIAS_RESIDUAL, x, D, stream));
+        } else {
+            OV_STEP(OV_PROF_GEMM_OUT, ov_gemm(h, D, w.out_w, D, w.out_b, x, D, M, D, D, OV_EPI_BIAS_RESIDUAL, x, D, 0, 0, 0, stream));
+        }
     }
-    OV_STEP(OV_PROF_LN, ov_layernorm_quant_fp8(x, D, w.ln2_w, w.ln2_b, q8, D, qs, M, D, c.ln_eps, stream));
-    if (h_mode >= 2) {
+    // ---- MLP half ----
+    if (f_fc) {
+        OV_STEP(OV_PROF_LN, ov_layernorm_quant_fp8(x, D, w.ln2_w, w.ln2_b, q8, D, qs, M, D, c.ln_eps, stream));
+    } else if (fold) {
+        OV_STEP(OV_PROF_LN, ov_rowstats(x, D, stats, M, D, c.ln_eps, stream));
+    } else {
+        OV_STEP(OV_PROF_LN, ov_layernorm(x, OV_BF16, D, w.ln2_w, w.ln2_b, h, OV_BF16, D, M, D, c.ln_eps, stream));
+    }
+    if (f_fc && f_proj && h_mode >= 2) {
         // static hidden scale: c_fc quantises its own output (e4m3 bytes, pitch F, in the `big` region), c_proj reads it as is
         unsigned char* h8 = (unsigned char*)big;
         OV_STEP(fc_cls, ov_gemm_fp8_static(q8, D, q.fc_w8, D, qs, nullptr, q.fc_s, q.fc_b, h8, F, h_amax, h_next, M, F, D, gelu, nullptr, 0, stream));
         OV_STEP(OV_PROF_GEMM_PROJ, ov_gemm_fp8_static(h8, F, q.proj_w8, F, nullptr, h_amax, q.proj_s, w.proj_b, x, D, nullptr, nullptr, M, D, F,
                                                       OV_EPI_BIAS_RESIDUAL, x, D, stream));
     } else {
-        OV_STEP(fc_cls, ov_gemm_fp8(q8, D, q.fc_w8, D, qs, q.fc_s, q.fc_b, big, ldb, M, F, D, gelu, nullptr, 0, stream));
-        OV_STEP(OV_PROF_LN, ov_quant_rows_fp8(big, ldb, q8, F, qs, M, F, h_mode == 1 ? h_amax : nullptr, stream));
-        OV_STEP(OV_PROF_GEMM_PROJ, ov_gemm_fp8(q8, F, q.proj_w8, F, qs, q.proj_s, w.proj_b, x, D, M, D, F, OV_EPI_BIAS_RESIDUAL, x, D, stream));
+        if (f_fc) OV_STEP(fc_cls, ov_gemm_fp8(q8, D, q.fc_w8, D, qs, q.fc_s, q.fc_b, big, ldb, M, F, D, gelu, nullptr, 0, stream));
+        else if (fold) OV_STEP(fc_cls, ov_gemm_ln(x, D, w.fc_w, D, w.fc_b, w.fc_colsum, stats, big, ldb, M, F, D, gelu, stream));
+        else OV_STEP(fc_cls, ov_gemm(h, D, w.fc_w, D, w.fc_b, big, ldb, M, F, D, gelu, nullptr, 0, 0, 0, 0, stream));
+        if (f_proj) {
+            OV_STEP(OV_PROF_LN, ov_quant_rows_fp8(big, ldb, q8, F, qs, M, F, (h_mode == 1 && f_fc) ? h_amax : nullptr, stream));
+            OV_STEP(OV_PROF_GEMM_PROJ, ov_gemm_fp8(q8, F, q.proj_w8, F, qs, q.proj_s, w.proj_b, x, D, M, D, F, OV_EPI_BIAS_RESIDUAL, x, D, stream));
+        } else {
+            OV_STEP(OV_PROF_GEMM_PROJ, ov_gemm(big, ldb, w.proj_w, F, w.proj_b, x, D, M, D, F, OV_EPI_BIAS_RESIDUAL, x, D, 0, 0, 0, stream));
+        }
     }
 #undef OV_STEP
     return OV_OK;
@@ -426,11 +471,11 @@ extern "C" int ov_tower_forward(const ov_tower* t, ov_bf16* x, int B, int L, voi
         float* hn = t->h_amax ? t->h_amax + 2 * c.layers + i : nullptr;
         float* an = t->h_amax ? t->h_amax + 3 * c.layers + i : nullptr;
         const int hm = t->h_amax ? t->h_mode : 0;
-        rc = fp8 ? run_block_fp8(c, t->blocks[i], t->fp8[i], x, h, big, q8, qs, ha, aa, hn, an, hm, Bm, L, stream, true)
+        rc = fp8 ? run_block_fp8(c, t->blocks[i], t->fp8[i], t->mask8[i], x, h, big, stats, q8, qs, ha, aa, hn, an, hm, Bm, L, stream, true)
                  : run_block(c, t->blocks[i], x, h, big, stats, Bm, L, stream, true);
         if (rc == OV_OK && nt > 0) {
-            rc = fp8 ? run_block_fp8(c, t->blocks[i], t->fp8[i], x + off * D, h + off * D, big + off * ldb, q8 + off * qw, qs + off,
-                                     ha, aa, hn, an, hm, nt, L, (ov_stream_t)tc->stream, false)
+            rc = fp8 ? run_block_fp8(c, t->blocks[i], t->fp8[i], t->mask8[i], x + off * D, h + off * D, big + off * ldb, stats + 2 * off,
+                                     q8 + off * qw, qs + off, ha, aa, hn, an, hm, nt, L, (ov_stream_t)tc->stream, false)
                      : run_block(c, t->blocks[i], x + off * D, h + off * D, big + off * ldb, stats + 2 * off, nt, L,
                                  (ov_stream_t)tc->stream, false);
         }

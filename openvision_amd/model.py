@@ -382,7 +382,7 @@ class ResidualAttentionBlock(nn.Module):
 class _TowerHandle:
     """ov_tower handle + the packed tensors it borrows (kept alive here)."""
 
-    def __init__(self, blocks, fp8: bool = False):
+    def __init__(self, blocks, fp8: bool = False, mask=None):
         lib = _lib.load()
         b0 = blocks[0]
         d = b0.attn.embed_dim
@@ -403,6 +403,10 @@ class _TowerHandle:
                 check(lib.ov_tower_set_block_fp8(self.handle, i, C.byref(b8)), "ov_tower_set_block_fp8")
         self.width, self.layers, self.fp8 = d, len(blocks), fp8
         self.h_amax = None
+        self.mask = [FP8_ALL] * len(blocks) if mask is None else list(mask)
+        if fp8 and mask is not None:
+            m8 = (C.c_ubyte * len(blocks))(*self.mask)
+            check(lib.ov_tower_set_fp8_mask(self.handle, m8, len(blocks)), "ov_tower_set_fp8_mask")
         if fp8:
             # per-layer running maxima of the MLP hidden and of the attention output: recorded while they are quantised row by row
             # (mode 1), then the static scales of the fused c_fc -> c_proj and attention -> out_proj hand-overs (mode 2)
@@ -413,7 +417,9 @@ class _TowerHandle:
     def freeze_fp8_scales(self, delayed: bool = True) -> None:
         if not self.fp8:
             raise _lib.OvhipError("freeze_fp8_scales: the tower is not in fp8 precision")
-        if not bool((self.h_amax[: 2 * self.layers] > 0).all()):
+        need = [(m & FP8_FC) and (m & FP8_PROJ) for m in self.mask] + [bool(m & FP8_OUT) for m in self.mask]   # scales the mask uses
+        seen = (self.h_amax[: 2 * self.layers] > 0).tolist()
+        if any(n and not s_ for n, s_ in zip(need, seen)):
             raise _lib.OvhipError("freeze_fp8_scales: run at least one forward in fp8 precision first (calibration)")
         check(_lib.load().ov_tower_set_fp8_hidden_scale(self.handle, ptr(self.h_amax), 2 if delayed else 3), "ov_tower_set_fp8_hidden_scale")
 
@@ -433,12 +439,25 @@ def _block_params(blocks):
     return ps
 
 
+FP8_QKV, FP8_OUT, FP8_FC, FP8_PROJ, FP8_ALL = 1, 2, 4, 8, 15      # ovhip.h OV_FP8_*: which GEMMs of a block take e4m3 operands
+PRECISIONS = ("bf16", "fp8", "fp8-mixed")
+
+
+def fp8_mixed_mask(layers: int):
+    """The "fp8-mixed" recipe (BASELINE.json config #5 inside a stated tolerance; DESIGN.md section 7, profiles/r03_fp8_ablation.md):
+    e4m3 operands where the per-GEMM ablation showed them cheap in accuracy and rich in time -- the two MLP products (c_fc -> c_proj, the
+    hidden handed over in e4m3 with a static scale) -- and bf16 for the attention projections (QKV, out_proj), whose quantisation is
+    what moves the embeddings on ill-conditioned ('sharp') weights.  OVHIP_FP8_MIXED_MASK (an OV_FP8_* bit set) overrides it."""
+    m = int(os.environ.get("OVHIP_FP8_MIXED_MASK", str(FP8_FC | FP8_PROJ)))
+    return [m & FP8_ALL] * layers
+
+
 def default_precision() -> str:
-    """GEMM operand precision of the block stacks: "bf16" (default) or "fp8" (OVHIP_PRECISION=fp8; e4m3 weights and
-    activations on the MX-scaled MFMA, BASELINE.json config #5)."""
+    """GEMM operand precision of the block stacks: "bf16" (default), "fp8" (OVHIP_PRECISION=fp8; e4m3 weights and activations on the
+    MX-scaled MFMA for all four GEMMs of a block, BASELINE.json config #5) or "fp8-mixed" (fp8_mixed_mask)."""
     p = os.environ.get("OVHIP_PRECISION", "bf16").lower()
-    if p not in ("bf16", "fp8"):
-        raise ValueError(f"OVHIP_PRECISION={p!r}: expected bf16 or fp8")
+    if p not in PRECISIONS:
+        raise ValueError(f"OVHIP_PRECISION={p!r}: expected one of {PRECISIONS}")
     return p
 
 
@@ -446,10 +465,17 @@ class _TowerCache:
     def __init__(self):
         self._pk = _Packed()
         self.precision = default_precision()
+        self.mask = None             # explicit per-layer OV_FP8_* masks (set_fp8_mask); None = what the precision name implies
 
     def get(self, blocks) -> _TowerHandle:
-        fp8 = self.precision == "fp8"
-        return self._pk.get(_block_params(blocks), lambda: _TowerHandle(blocks, fp8=fp8), extra=(fp8,))
+        fp8 = self.precision != "bf16"
+        mask = None
+        if fp8:
+            mask = self.mask if self.mask is not None else (fp8_mixed_mask(len(blocks)) if self.precision == "fp8-mixed" else None)
+            if mask is not None and len(mask) != len(blocks):
+                mask = (list(mask) + [mask[-1]] * len(blocks))[: len(blocks)]        # sub-stacks (exploded forward): layer-wise prefix
+        key = (fp8, None if mask is None else tuple(mask))
+        return self._pk.get(_block_params(blocks), lambda: _TowerHandle(blocks, fp8=fp8, mask=mask), extra=key)
 
 
 def _run_blocks(blocks, x: torch.Tensor, cache: Optional[_TowerCache] = None, ws: Optional[_Workspace] = None):
@@ -488,11 +514,15 @@ class Transformer(nn.Module):
     def tower(self) -> _TowerHandle:
         return self._cache.get(list(self.resblocks))
 
-    def set_precision(self, precision: str) -> None:
-        """"bf16" or "fp8": operand precision of this stack's four GEMMs per block (the tower is re-packed on next use)."""
-        if precision not in ("bf16", "fp8"):
-            raise ValueError("precision must be 'bf16' or 'fp8'")
+    def set_precision(self, precision: str, mask=None) -> None:
+        """"bf16", "fp8" (all four GEMMs of every block in e4m3) or "fp8-mixed" (fp8_mixed_mask); `mask`: an OV_FP8_* bit set for
+        every layer, or one per layer, instead of what the name implies.  The tower is re-packed on next use."""
+        if precision not in PRECISIONS:
+            raise ValueError(f"precision must be one of {PRECISIONS}")
+        if mask is not None and precision == "bf16":
+            raise ValueError("an fp8 mask needs an fp8 precision")
         self._cache.precision = precision
+        self._cache.mask = None if mask is None else ([int(mask)] * self.layers if isinstance(mask, int) else [int(v) for v in mask])
 
     def freeze_fp8_scales(self, delayed: bool = True) -> None:
         """fp8 precision: after at least one forward (which records the per-layer maximum of the MLP hidden), switch c_fc -> c_proj to
@@ -685,11 +715,12 @@ class CLIP(nn.Module):
                              self.ln_final.bias, self.text_projection), build)
 
     # -- reference API -----------------------------------------------------------------------------------
-    def set_precision(self, precision: str) -> None:
-        """GEMM operand precision of both block stacks: "bf16" (default) or "fp8" (e4m3 weights and activations on the MX-scaled
-        MFMA; embedding, heads, attention, LayerNorm statistics and the loss stay as they are)."""
-        self.visual.transformer.set_precision(precision)
-        self.transformer.set_precision(precision)
+    def set_precision(self, precision: str, mask=None) -> None:
+        """GEMM operand precision of both block stacks: "bf16" (default), "fp8" (e4m3 weights and activations on the MX-scaled MFMA
+        for all four GEMMs of every block) or "fp8-mixed" (e4m3 for the MLP products only: model.fp8_mixed_mask); `mask` = an explicit
+        OV_FP8_* bit set instead.  Embedding, heads, attention, LayerNorm statistics and the loss stay as they are."""
+        self.visual.transformer.set_precision(precision, mask)
+        self.transformer.set_precision(precision, mask)
 
     def freeze_fp8_scales(self, delayed: bool = True) -> None:
         """fp8 precision, after a calibration forward of both towers: static scales for the MLP hidden (see Transformer)."""

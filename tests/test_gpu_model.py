@@ -92,9 +92,11 @@ def tiny_sharp():
 
 
 def test_tiny_testcat_table_topk(tiny_sharp):
-    """ov-zero-shot-test.py:176-192 on the 5 testcat images x 9 caption rows ('sharp' weights): the whole per-image ranking and the
-    per-text best image must equal the reference's (north_star: top-k indices bit-exact).  Not vacuous: the number of ranks the
-    reference decides with margin is asserted first (the fixture gives all 8 per row)."""
+    """ov-zero-shot-test.py:176-192 on the 5 testcat images x 9 caption rows ('sharp' weights): the whole per-image ranking and each
+    image's best caption must equal the reference's (north_star: top-k indices bit-exact).  Not vacuous in the ranks -- the number
+    the reference decides with margin is asserted first (all 8 per row) -- but NOT image-sensitive: on these weights the five
+    pictures (one photograph, different captions drawn on it) rank the captions alike.  The image-dependent table, the script's
+    second table (best image per text) and the checkpoint-directory loading are test_zero_shot_cli_from_checkpoint_directory."""
     m = tiny_sharp
     g = golden("tiny16_160_testcat.npz")
     assert str(g["variant"]) == "sharp"
@@ -118,6 +120,65 @@ def test_tiny_testcat_table_topk(tiny_sharp):
     probs = (float(m.logit_scale.exp()) * cos).softmax(dim=-1)
     assert np.array_equal(probs.argmax(dim=-1).numpy(), g["best"])
     np.testing.assert_allclose(probs.numpy(), g["probs"], atol=0.05)
+
+
+def test_zero_shot_cli_from_checkpoint_directory(tmp_path):
+    """SURVEY 8f row 1 + row a8, end to end and image-sensitive: weights -> checkpoint.save_pretrained (open_clip_config.json +
+    open_clip_pytorch_model.bin, what ov-zero-shot-test.py:37-56 loads) -> `python -m openvision_amd.zero_shot` on the five testcat PNG
+    files with nine real prompts (tokenised by the CLI's own tokenizer) -> its PRINTED tables against the reference's
+    (tests/golden/tiny16_160_testcat_cli.npz, make_golden.gen_testcat_cli: the reference model on the same files, prompts tokenised by
+    the `tokenizers` library): every cosine within gap / 2, each image's decided leading ranks (>= 3 per row, all five rows
+    different), and the script's second table, best image per text (ov-zero-shot-test.py:198-208), whose nine winners cover all five
+    images.  A swapped, repeated or input-independent image embedding fails both tables."""
+    import subprocess
+    import sys
+    from openvision_amd import checkpoint
+    g = golden("tiny16_160_testcat_cli.npz")
+    gap = float(g["gap"])
+    ref, names, prompts = g["cosine"], [str(n) for n in g["names"]], [str(t) for t in g["prompts"]]
+    # the fixture's own properties first (a test that cannot fail proves nothing)
+    ks = [_leading_ranks(r, gap) for r in ref]
+    assert min(ks) >= 3 and len({tuple(g["argsort"][r][:3].tolist()) for r in range(5)}) >= 3
+    assert len(set(g["best_image_per_text"].tolist())) >= 4
+    col = np.sort(ref, axis=0)
+    assert (col[-1] - col[-2]).min() >= gap and float(g["cos_err_ref_bf16"]) < gap / 2
+    cfg = preset("vit-tiny-patch16-160")
+    sd = synth.make_state_dict(cfg, 0, "sharp")
+    sd["visual.proj"] = torch.from_numpy(g["visual_proj"])
+    sd["text_projection"] = torch.from_numpy(g["text_projection"])
+    model = create_model(cfg, device=DEV, state_dict=sd)
+    ckpt = str(tmp_path / "ckpt")
+    checkpoint.save_pretrained(model, cfg, ckpt, safetensors=False, torch_bin=True)
+    assert sorted(os.listdir(ckpt)) == ["open_clip_config.json", "open_clip_pytorch_model.bin"]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-m", "openvision_amd.zero_shot", "--use_model", ckpt, "--image_dir",
+                        os.path.join(root, "tests", "golden", "testcat_160"), "--prompts", "|".join(prompts)],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=root, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = p.stdout
+    assert "Visual Config Used:" in out and "Pool type:             avg" in out
+    table, best, cur, sect = {}, {}, None, None
+    for line in out.splitlines():
+        if line.startswith("=== "):
+            sect = line
+        elif line.startswith("--- ") and line.endswith(" ---"):
+            cur = line[4:-4]
+            table[cur] = []
+        elif "cosine:" in line and cur is not None and "Cosine" in (sect or ""):
+            lab, rest = line.split("cosine:")
+            table[cur].append((lab.strip(), float(rest.split("prob:")[0])))
+        elif " <- " in line and "Best Image" in (sect or ""):
+            lab, rest = line.split(" <- ")
+            best[lab.strip()] = rest.split("(")[0].strip()
+    assert list(table) == names                                      # sorted directory listing, as the script
+    for r, n in enumerate(names):
+        assert len(table[n]) == len(prompts)
+        got = {lab: c for lab, c in table[n]}
+        for j, t in enumerate(prompts):
+            assert abs(got[t] - ref[r, j]) < gap / 2, (n, t, got[t], ref[r, j])
+        order = [prompts.index(lab) for lab, _ in table[n]]          # printed in descending cosine
+        assert order[:ks[r]] == g["argsort"][r][:ks[r]].tolist(), (n, order, g["argsort"][r])
+    assert {t: names[int(g["best_image_per_text"][j])] for j, t in enumerate(prompts)} == best
 
 
 def _block_prefix_tokens(m, img, upto):

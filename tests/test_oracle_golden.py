@@ -1,5 +1,7 @@
 """CPU: the oracle (oracle/clip_ref.py) against the golden vectors the REFERENCE produced
 (tests/golden/make_golden.py).  This is what pins the oracle; fp32, tight tolerances."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -73,6 +75,38 @@ def test_tiny_testcat_zero_shot_table():
     close(probs, g["probs"], 2e-5)
     assert np.array_equal(order.numpy(), g["argsort"])            # top-k indices bit-exact
     assert np.array_equal(probs.argmax(-1).numpy(), g["best"])
+
+
+def test_tiny_testcat_cli_table_from_the_png_files():
+    """The image-sensitive zero-shot fixture (make_golden.gen_testcat_cli): the oracle on the committed PNG files (ToTensor + Normalize,
+    the script's Resize((160, 160)) being the identity on them), the fixture's two replaced projections and its token rows reproduces
+    the reference's cosine table, every decided rank and both of the script's decisions (best text per image, best image per text);
+    the CLI's own tokenizer gives the fixture's token rows for the nine prompts."""
+    from PIL import Image
+    from openvision_amd.tokenizer import WordPieceTokenizer
+    cfg = ovcfg.preset("vit-tiny-patch16-160")
+    g = golden("tiny16_160_testcat_cli.npz")
+    sd = synth.make_state_dict(cfg, 0, "sharp")
+    sd["visual.proj"], sd["text_projection"] = T(g["visual_proj"]), T(g["text_projection"])
+    pp = ovcfg.DEFAULT_PREPROCESS
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "testcat_160")
+    assert sorted(os.listdir(here)) == [str(n) for n in g["names"]]
+    arr = [(np.asarray(Image.open(os.path.join(here, str(n))).convert("RGB"), dtype=np.float32) / 255.0 - np.asarray(pp["mean"], np.float32))
+           / np.asarray(pp["std"], np.float32) for n in g["names"]]
+    img = T(np.stack(arr).transpose(0, 3, 1, 2).copy())
+    tok = WordPieceTokenizer(None, context_length=80)([str(t) for t in g["prompts"]])
+    assert np.array_equal(tok.numpy(), g["tokens"])
+    cos, probs, order = R.zero_shot_table(R.encode_image(img, sd, cfg), R.encode_text(tok, sd, cfg), sd["logit_scale"])
+    close(cos, g["cosine"], 2e-5)                                  # the projections amplify fp32 summation-order noise ~10x
+    gap = float(g["gap"])
+    for r in range(cos.shape[0]):
+        k = 0
+        srt = np.sort(g["cosine"][r])[::-1]
+        while k + 1 < len(srt) and srt[k] - srt[k + 1] > gap:
+            k += 1
+        assert k >= 3 and np.array_equal(order[r, :k].numpy(), g["argsort"][r][:k])
+    assert np.array_equal(probs.argmax(-1).numpy(), g["best_text_per_image"])
+    assert np.array_equal(probs.argmax(0).numpy(), g["best_image_per_text"])
 
 
 @pytest.mark.timeout(600)
