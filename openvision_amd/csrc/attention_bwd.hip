@@ -114,7 +114,7 @@ __global__ __launch_bounds__(640) void attn_bwd_hd64(const AttnBwdArgs a) {
         const int query = i * 32 + r;
         bf16x8_t qB[4], dB[4];
 #pragma unroll
-        for (int st = 0; st < 4; ++st) { qB[st] = frag(qimg, i, st); dB[st] = frag(dimg, i, st); }
+        for (int st = 0; st < 4; ++st) qB[st] = frag(qimg, i, st);      // (dB is read behind pass 1: 16 registers fewer across it)
         // pass 1: lse (log2 units) of row `query`; a lane sees the keys (t&3) + 8 (t>>2) + 4 h2 of each tile
         // (SAVED: the forward kept it -- no score pass, no exponentials here)
         float m = -INFINITY, l = 0.f;
@@ -140,6 +140,8 @@ __global__ __launch_bounds__(640) void attn_bwd_hd64(const AttnBwdArgs a) {
                 m = mn;
             }
         }
+#pragma unroll
+        for (int st = 0; st < 4; ++st) dB[st] = frag(dimg, i, st);
         float lse2;
         if (SAVED) {
             // the forward writes entries [0, L) only (padded query lanes re-store row L - 1 at index L - 1): entries [L, KC) are

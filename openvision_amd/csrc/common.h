@@ -210,3 +210,21 @@ __device__ __forceinline__ u32x4_t epi_combine(u32x4_t o, u32x4_t r) {
     }
     return out;
 }
+
+// 16-byte output store with a compile-time cache policy: 0 = plain, 1 = sc1 (write-through; the line is not kept in the XCD's L2 --
+// MI355X_MICROARCH.md, store flavours), 2 = nt (streaming), 4 = sc0 sc1.  A tile's 128 KiB of output otherwise displace the W slice /
+// A panels the next K-tiles are about to be fetched from (32 CUs x 128 KiB = the whole 4 MiB L2 of an XCD per round of tiles).
+#ifndef OVHIP_ST_LDS
+#define OVHIP_ST_LDS 2          /* policy of the LDS-transposed (whole-line) epilogue's stores */
+#endif
+#ifndef OVHIP_ST_DIRECT
+#define OVHIP_ST_DIRECT 2       /* policy of the direct (row-per-lane, half-line) epilogue's stores */
+#endif
+template <int POLICY>
+__device__ __forceinline__ void store16(void* dst, u32x4_t v) {
+    if (POLICY == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(dst), "v"(v) : "memory");
+    else if (POLICY == 2) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" :: "v"(dst), "v"(v) : "memory");
+    else if (POLICY == 4) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(dst), "v"(v) : "memory");
+    else *(u32x4_t*)dst = v;
+}
+

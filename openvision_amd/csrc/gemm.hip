@@ -650,23 +650,6 @@ constexpr int PRM_OFF = SMEM_BYTES;                  // two 4-KiB parameter bloc
 constexpr int IMG_OFF = PRM_OFF + 2 * 4096;          // DIRECT == false only: 8 wave-local 2-KiB transposition images (16 rows x 64 n bf16)
 constexpr int SMEM_PERSIST = IMG_OFF + 8 * 2048;     // 152 KiB of the CU's 160 (136 KiB without the images)
 
-// 16-byte output store with a compile-time cache policy: 0 = plain, 1 = sc1 (write-through; the line is not kept in the XCD's L2 --
-// MI355X_MICROARCH.md, store flavours), 2 = nt (streaming), 4 = sc0 sc1.  A tile's 128 KiB of output otherwise displace the W slice /
-// A panels the next K-tiles are about to be fetched from (32 CUs x 128 KiB = the whole 4 MiB L2 of an XCD per round of tiles).
-#ifndef OVHIP_ST_LDS
-#define OVHIP_ST_LDS 2          /* policy of the LDS-transposed (whole-line) epilogue's stores */
-#endif
-#ifndef OVHIP_ST_DIRECT
-#define OVHIP_ST_DIRECT 2       /* policy of the direct (row-per-lane, half-line) epilogue's stores */
-#endif
-template <int POLICY>
-__device__ __forceinline__ void store16(ov_bf16* dst, u32x4_t v) {
-    if (POLICY == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(dst), "v"(v) : "memory");
-    else if (POLICY == 2) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" :: "v"(dst), "v"(v) : "memory");
-    else if (POLICY == 4) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(dst), "v"(v) : "memory");
-    else *(u32x4_t*)dst = v;
-}
-
 // Epilogue of the persistent kernel.  After the MFMAs a lane (fr = lane & 15, fq = lane >> 4) holds, for each of its 8 fragment rows i
 // and 4 column blocks j, four consecutive n of ONE output row: acc[i][j][0..3] = C[i*16 + fr][j*16 + fq*4 + 0..3].  Packed to bf16
 // that is 8 bytes per (i, j).  Two v_permlane16_swap per pair of column blocks (j0, j0 + 1) exchange the 8 bytes of block j0 + 1 in

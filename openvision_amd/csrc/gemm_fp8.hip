@@ -46,18 +46,44 @@ struct Fp8Args {
     float* amax_next;          // MODE 1, optional: running maximum of |C| before quantisation (the NEXT call's scale: delayed scaling)
 };
 
+template <int V> struct IntC { static constexpr int value = V; };
+
+// The lane id, recomputed where it is needed (two VALU instructions) and opaque to CSE: as ONE value defined at kernel entry it is live
+// through every K-tile variant and epilogue, and in this kernel -- at the register limit -- it was what got spilled: a scratch reload
+// inside the epilogue is a vector-memory operation the hand-counted vmcnt waits do not know about.
+__device__ __forceinline__ int fresh_lane() {
+    int l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(l));
+    return l;
+}
+
+// Maximum over the wave without index registers (DPP patterns + the two permlane swaps): __shfl_xor's six bpermute indices are
+// loop invariants of the whole kernel -- hipcc hoisted them to the kernel entry and spilled all six here.
+__device__ __forceinline__ float wave_max_noidx(float v) {
+    auto dpp = [](float x, auto ctrl) {
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xf, 0xf, false));
+    };
+    v = fmaxf(v, dpp(v, IntC<0xB1>{}));        // quad_perm [1, 0, 3, 2]
+    v = fmaxf(v, dpp(v, IntC<0x4E>{}));        // quad_perm [2, 3, 0, 1]
+    v = fmaxf(v, dpp(v, IntC<0x141>{}));       // row_half_mirror: all 8
+    v = fmaxf(v, dpp(v, IntC<0x140>{}));       // row_mirror: all 16
+    const u32x2_t a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));        // rows {0, 1} and {2, 3}
+    const u32x2_t b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
 constexpr float HEADROOM = 2.0f;   // static activation scales leave one binade above the calibrated maximum (e4m3 is floating point:
                                    // head room costs range at the bottom, not precision)
 
-template <int V> struct IntC { static constexpr int value = V; };
 
 // MODE 0: per-row scales from the parameter block, bf16 output.  MODE 1: same, output quantised to e4m3 with the static scale
 // HEADROOM * amax_out / 448 (feeds the next fp8 GEMM without a bf16 round trip).  MODE 2: one static input scale, bf16 output.
 template <int EPI, int MODE>
 __device__ __forceinline__ void epilogue_fp8(const Fp8Args& g, f32x4_t (&acc)[8][4], char* img, const char* prm, int64_t m0, int n0,
                                              int wave, int lane_in, bool edge, float rs_const, float inv_out, float next_thr) {
-    int lane = lane_in;
-    asm volatile("" : "+v"(lane));       // opaque: the epilogue's per-lane addresses are recomputed per tile, not carried (and spilled)
+    (void)lane_in;
+    const int lane = fresh_lane();       // opaque: the epilogue's per-lane addresses are recomputed per tile, not carried (and spilled)
                                          // through the main loop as loop invariants
     const int wm = wave >> 2, wn = wave & 3;
     const int fr = lane & 15, fq = lane >> 4;
@@ -76,10 +102,7 @@ __device__ __forceinline__ void epilogue_fp8(const Fp8Args& g, f32x4_t (&acc)[8]
                                                     // destination must never be spilled before its data has landed
         }
     };
-    if (EPI == OV_EPI_BIAS_RESIDUAL) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) load_resid(i);
-    }
+    if (EPI == OV_EPI_BIAS_RESIDUAL) { load_resid(0); load_resid(1); }
     f32x4_t bq[4], cq[4];
     float rsq[8];
     const unsigned pa = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(prm + (wn * 64 + fq * 4) * 4);
@@ -96,7 +119,6 @@ __device__ __forceinline__ void epilogue_fp8(const Fp8Args& g, f32x4_t (&acc)[8]
           "=&v"(rsq[0]), "=&v"(rsq[1]), "=&v"(rsq[2]), "=&v"(rsq[3]), "=&v"(rsq[4]), "=&v"(rsq[5]), "=&v"(rsq[6]), "=&v"(rsq[7])
         : "v"(pa), "v"(ra)
         : "memory");
-    const bool has_bias = g.bias != nullptr;
     char* const wr = img + fr * 128 + (fq & 1) * 8;
     const int wsw = fr & 7;
     const char* const rd = img + er * 128 + ((ec ^ er) << 4);
@@ -113,24 +135,21 @@ __device__ __forceinline__ void epilogue_fp8(const Fp8Args& g, f32x4_t (&acc)[8]
                                        bf16hi_to_f32(o[e]) + bf16hi_to_f32(rv[i][it][e]));
             }
             const unsigned m = (unsigned)m0 + wm * 128 + i * 16 + it * 8 + er;
-            if (m < (unsigned)g.M && ncol) *(u32x4_t*)(g.C + (int64_t)m * g.ldc + n) = o;
+            if (m < (unsigned)g.M && ncol) store16<OVHIP_ST_LDS>(g.C + (int64_t)m * g.ldc + n, o);
         }
     };
-    auto wait_resid = [&](int, int, int) {};
 #pragma unroll
     for (int i = 0; i <= 8; ++i) {
-        if (EPI == OV_EPI_BIAS_RESIDUAL && i == 4) {
-#pragma unroll
-            for (int k = 4; k < 8; ++k) load_resid(k);
-        }
+        // residual rows two passes ahead of their use (pass i stores row i - 1): 16 registers in flight, compiler-managed waits
+        if (EPI == OV_EPI_BIAS_RESIDUAL && i >= 1 && i + 1 < 8 && (i & 1)) { load_resid(i + 1); load_resid(i + 2 < 8 ? i + 2 : 7); }
         if (i < 8) {
             const f32x2_t rs = {MODE == 2 ? rs_const : rsq[i], MODE == 2 ? rs_const : rsq[i]};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 f32x2_t v01 = f32x2_t{acc[i][j][0], acc[i][j][1]} * rs;
                 f32x2_t v23 = f32x2_t{acc[i][j][2], acc[i][j][3]} * rs;
-                const f32x2_t b01 = {has_bias ? bq[j][0] : 0.f, has_bias ? bq[j][1] : 0.f};
-                const f32x2_t b23 = {has_bias ? bq[j][2] : 0.f, has_bias ? bq[j][3] : 0.f};
+                const f32x2_t b01 = {bq[j][0], bq[j][1]};          // (no bias: the kernel zeroed the slots' bias rows at its start)
+                const f32x2_t b23 = {bq[j][2], bq[j][3]};
                 v01 = __builtin_elementwise_fma(v01, f32x2_t{cq[j][0], cq[j][1]}, b01);
                 v23 = __builtin_elementwise_fma(v23, f32x2_t{cq[j][2], cq[j][3]}, b23);
                 if (EPI == OV_EPI_BIAS_GELU_ERF) gelu_erf_f2x2(v01, v23);
@@ -156,16 +175,11 @@ __device__ __forceinline__ void epilogue_fp8(const Fp8Args& g, f32x4_t (&acc)[8]
             if (i > 0) {
                 const unsigned m = (unsigned)m0 + wm * 128 + (i - 1) * 16 + (lane >> 2);
                 const int n8 = n0 + wn * 64 + (lane & 3) * 16;
-                if (m < (unsigned)g.M && n8 < g.N) *(u32x4_t*)((unsigned char*)g.C + (int64_t)m * g.ldc + n8) = vo[i - 1][0];
+                if (m < (unsigned)g.M && n8 < g.N) store16<OVHIP_ST_LDS>((unsigned char*)g.C + (int64_t)m * g.ldc + n8, vo[i - 1][0]);
             }
             if (i < 8) vo[i][0] = *(const u32x4_t*)(img + (lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 3) & 3)) << 4));
         } else {
-            if (EPI == OV_EPI_BIAS_RESIDUAL) {
-                if (i == 4) { wait_resid(0, 4, 8); put(0); put(1); put(2); put(3); }
-                else if (i > 4) { wait_resid(i - 1, i, 14); put(i - 1); }
-            } else if (i > 0) {
-                put(i - 1);
-            }
+            if (i > 0) put(i - 1);
             if (i < 8) {
                 vo[i][0] = *(const u32x4_t*)(rd);
                 vo[i][1] = *(const u32x4_t*)(rd + 1024);
@@ -173,8 +187,7 @@ __device__ __forceinline__ void epilogue_fp8(const Fp8Args& g, f32x4_t (&acc)[8]
         }
     }
     if (MODE == 1 && g.amax_next != nullptr) {       // delayed scaling: this tile's maximum feeds the next call's scale
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o, 64));
+        lmax = wave_max_noidx(lmax);
         // next_thr = the value at kernel start: a load here would make the compiler wait for this epilogue's stores to be acknowledged
         if (lane == 0 && lmax > next_thr) atomicMax((unsigned*)g.amax_next, __float_as_uint(lmax));
     }
@@ -202,24 +215,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_fp8_persist(const Fp8Args g)
     // Lane i of an instruction lands at row 8 g + (i >> 3), physical chunk i & 7, which holds logical chunk (i & 7) ^ (row & 7).
     // Per-lane byte offsets of this lane's 2 DMA rows of every piece from the tile's A / W base: the same for every tile.  Rows
     // past M / N are clamped at issue time: off = min(off, last_row * ld + chunk), exact because chunk < ld.
-    unsigned offa[4], offw[4];
-    unsigned dch16;
-    auto compute_offsets = [&]() {            // recomputed per tile from an opaque lane id: not carried through the epilogue in registers
-        int ln = threadIdx.x & 63;
-        asm volatile("" : "+v"(ln));
-        const int dr = ln >> 3;
-        const int dc = (ln & 7) ^ dr;
-        dch16 = dc * 16;
-#pragma unroll
-        for (int half = 0; half < 2; ++half)
-#pragma unroll
-            for (int gi = 0; gi < 2; ++gi) {
-                const int r = 8 * (wave + 8 * gi) + dr;
-                offa[half * 2 + gi] = (unsigned)(((r >> 6) * 128 + half * 64 + (r & 63)) * g.lda + dc * 16);   // piece A m-half `half`
-                offw[half * 2 + gi] = (unsigned)(((r >> 5) * 64 + half * 32 + (r & 31)) * g.ldw + dc * 16);    // piece W n-half `half`
-            }
-    };
-    compute_offsets();
+    // DMA offsets are NOT kept in registers: every stage_piece rebuilds its two from an opaque lane id (7 VALU instructions) -- as
+    // loop invariants hipcc carried them (zero-extended to 64 bits, through every K-tile variant and the epilogue) and spilled ~30
+    // registers, and a spill reload inside the K loop is a vector-memory operation the hand-counted vmcnt waits do not know about
     struct TileBase { const unsigned char* a; const unsigned char* w; unsigned lima, limw; };   // wave-uniform
     TileBase cur, nxt;
     int64_t m0, nm0 = 0;
@@ -242,9 +240,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_fp8_persist(const Fp8Args g)
         char* dst = sbase + boff + p * PIECE;
         const bool isa = (p == 0 || p == 3);
         const unsigned char* b = isa ? tb.a : tb.w;
+        const int ln = fresh_lane();
+        const int dr = ln >> 3;                                  // DMA row within the 8-row instruction
+        const unsigned dch16 = (unsigned)(((ln & 7) ^ dr) << 4); // logical 16-byte chunk this lane fetches (the image is XOR-swizzled)
         const unsigned lim = (isa ? tb.lima : tb.limw) + dch16;
-        unsigned o0 = p == 0 ? offa[0] : p == 3 ? offa[2] : p == 1 ? offw[0] : offw[2];
-        unsigned o1 = p == 0 ? offa[1] : p == 3 ? offa[3] : p == 1 ? offw[1] : offw[3];
+        // instruction w of the piece = its rows 8 w .. 8 w + 7; A piece (m-half h): tile rows h * 64 + r (r < 64), + 128 for w + 8;
+        // W piece (n-half h): tile rows (r >> 5) * 64 + h * 32 + (r & 31) with r = 8 w + dr, + 128 for w + 8
+        const unsigned ld = (unsigned)(isa ? g.lda : g.ldw);
+        const unsigned urow = isa ? (unsigned)(8 * wave + (p == 3 ? 64 : 0)) : (unsigned)((wave >> 2) * 64 + 8 * (wave & 3) + (p == 2 ? 32 : 0));
+        unsigned o0 = ((unsigned)dr + urow) * ld + dch16;
+        unsigned o1 = o0 + 128u * ld;
         o0 = o0 < lim ? o0 : lim;
         o1 = o1 < lim ? o1 : lim;
         __builtin_amdgcn_global_load_lds((gptr_t)(b + o0), (lptr_t)dst, 16, 0, 0);
@@ -252,6 +257,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_fp8_persist(const Fp8Args g)
     };
     auto stage_params = [&](int slot, int64_t mm, int nn) {
         char* dst = smem + PRM_OFF + slot * 4096;
+        const int lane = fresh_lane();
         int c = nn + lane * 4;
         c = c + 4 <= g.N ? c : g.N - 4;
         if (wave == 0 && g.bias != nullptr) __builtin_amdgcn_global_load_lds((gptr_t)(g.bias + c), (lptr_t)dst, 16, 0, 0);
@@ -269,11 +275,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_fp8_persist(const Fp8Args g)
     const int wm = wave >> 2, wn = wave & 3;
     const int fr = lane & 15, fq = lane >> 4;
     // fragment reads: operand row `row` of a piece, logical chunks 2 fq and 2 fq + 1 -> physical chunk ^ (row & 7) = ^ (fr & 7)
-    const int c0 = ((2 * fq) ^ (fr & 7)) << 4, c1 = ((2 * fq + 1) ^ (fr & 7)) << 4;
-    const int a_row = (wm * 64 + fr) * 128;                          // + (i & 3) * 16 * 128 within piece A(mh)
-    const int w_row = (wn * 32 + fr) * 128;                          // + (j & 1) * 16 * 128 within piece W(nh)
+    // fragment addressing, rebuilt per tile from an opaque lane id (not carried through the epilogue in registers)
+    int c0, c1, a_row, w_row;
+    auto frag_consts = [&]() {
+        const int ln = fresh_lane();
+        const int r = ln & 15, q = ln >> 4;
+        c0 = ((2 * q) ^ (r & 7)) << 4;
+        c1 = ((2 * q + 1) ^ (r & 7)) << 4;
+        a_row = (wm * 64 + r) * 128;                                 // + (i & 3) * 16 * 128 within piece A(mh)
+        w_row = (wn * 32 + r) * 128;                                 // + (j & 1) * 16 * 128 within piece W(nh)
+    };
     const int nt = g.K / BKB;                                        // >= 3 (launcher)
 
+    if (g.bias == nullptr && tid < 256) {                             // no bias: both parameter slots read zeros (never DMA'd over)
+        *(float*)(smem + PRM_OFF + tid * 4) = 0.f;
+        *(float*)(smem + PRM_OFF + 4096 + tid * 4) = 0.f;
+    }
     set_tile(tcur, cur, m0, n0);
 #pragma unroll
     for (int p = 0; p < 4; ++p) stage_piece(cur, 0, p);
@@ -350,7 +367,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_fp8_persist(const Fp8Args g)
         const int tnext = tcur + nper;
         has_next = tnext < xcnt;
         if (has_next) set_tile(tnext, nxt, nm0, nn0);
-        if (titer++ > 0) compute_offsets();
+        ++titer;
+        frag_consts();
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll

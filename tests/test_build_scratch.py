@@ -15,6 +15,11 @@ from openvision_amd import build as B
 GUARDED = {
     "gemm.hip": r"gemm_bf16_persist|gemm_bf16_pp",
     "attention.hip": r"attn_fwd_hd64_persist|attn_fwd_hd64_stream",
+    # round 3: the fp8 GEMM (LDS-DMA + counted vmcnt like the bf16 kernel; it carried 120-140 B of scratch, reloaded INSIDE the K loop
+    # behind vmcnt(0)) and the resident attention backward (no counted waits, but at its 168-register limit: kept at zero so that a
+    # later asm load cannot land in a spilling kernel unnoticed)
+    "gemm_fp8.hip": r"gemm_fp8_persist",
+    "attention_bwd.hip": r"attn_bwd_hd64",
 }
 
 
