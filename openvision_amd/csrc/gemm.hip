@@ -1227,6 +1227,147 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist(const GemmArgs 
     }
 }
 
+// =====================================================================================================
+// Skinny kernel: the small-M path (ov-zero-shot-test.py:167-195 encodes ONE image per call: M = 257 rows at L/14).  There the 256 x 256
+// kernels put 8-32 workgroups on 256 CUs and every one of them walks its whole K extent one K-tile ahead of the HBM latency of the
+// weights (4.7 ms per L/14 image, profiles/r02_probes.log).  Here a workgroup is 4 waves on a 64 x 64 tile (80-320 workgroups for
+// the L/14 shapes at M = 257), operands arrive through a ring of FOUR LDS stages by LDS-DMA in whole 128-byte lines, three K-tiles
+// ahead (counted vmcnt, one raw barrier per K-tile), so the weight stream is pulled by all CUs at once and its latency is covered.
+// NO split-K: every output element accumulates its K products in the same order, through the same v_mfma_f32_16x16x32_bf16 (W as
+// the A operand, k 0-31 then 32-63 of each K-tile), as in the 256 x 256 kernels, and the epilogue applies the same functions -- a
+// row's result is bitwise the same whichever kernel computed it (batch 1 against batch 9: test_batch_invariance...).
+// LDS image of a stage: [A 64 rows x 128 B][W 64 rows x 128 B], 16-byte chunk c of row r stored at chunk c ^ (r & 7) (on the DMA source
+// side and on the read side), conflict-free for the 16x16x32 operand reads (the v1 kernel's image).
+constexpr int SK_BM = 64, SK_BN = 64, SK_STAGES = 4;
+constexpr int SK_STAGE_BYTES = (SK_BM + SK_BN) * 128;            // 16 KiB
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16_skinny(const GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) char smem[SK_STAGES * SK_STAGE_BYTES];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tn = blockIdx.x % g.tiles_n, tm = blockIdx.x / g.tiles_n;          // n fastest: neighbours share the A rows in L2
+    const int64_t m0 = (int64_t)tm * SK_BM;
+    const int n0 = tn * SK_BN;
+
+    // staging: wave w issues, per K-tile, A instructions 2 w, 2 w + 1 and W instructions 2 w, 2 w + 1 (8 rows x 128 B each)
+    const ov_bf16* asrc[2];
+    const ov_bf16* wsrc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (2 * wave + j) * 8 + (lane >> 3);
+        const int ch = (lane & 7) ^ (row & 7);
+        int64_t ar = m0 + row;
+        ar = ar < g.M ? ar : g.M - 1;                 // clamp: tail rows load a valid row, never stored
+        int wr = n0 + row;
+        wr = wr < g.N ? wr : g.N - 1;
+        asrc[j] = g.A + ar * g.lda + ch * 8;
+        wsrc[j] = g.W + (int64_t)wr * g.ldw + ch * 8;
+    }
+    auto stage = [&](int t) {
+        char* dst = smem + (t & (SK_STAGES - 1)) * SK_STAGE_BYTES + wave * 2048;
+        const int k0 = t * BK;
+        __builtin_amdgcn_global_load_lds((gptr_t)(asrc[0] + k0), (lptr_t)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(asrc[1] + k0), (lptr_t)(dst + 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[0] + k0), (lptr_t)(dst + SK_BM * 128), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[1] + k0), (lptr_t)(dst + SK_BM * 128 + 1024), 16, 0, 0);
+    };
+    // wave (wm, wn) owns rows wm * 32 .. + 32, columns wn * 32 .. + 32 of the tile: 2 x 2 accumulator fragments
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int a_off = (wm * 32 + fr) * 128;
+    const int w_off = SK_BM * 128 + (wn * 32 + fr) * 128;
+    const int sw0 = (fq ^ (fr & 7)) << 4, sw1 = ((4 + fq) ^ (fr & 7)) << 4;          // rows fr and fr + 16 share (row & 7)
+
+    f32x4_t acc[2][2];
+    const int nt = g.K / BK;
+    for (int t = 0; t < 3 && t < nt; ++t) stage(t);
+    for (int t = 0; t < nt; ++t) {
+        // K-tile t has landed once at most min(2, nt - 1 - t) younger K-tiles (4 DMAs each) are still in flight
+        const int ahead = nt - 1 - t;
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                     // everyone's pieces of K-tile t are in; everyone has read K-tile t - 1
+        if (t + 3 < nt) stage(t + 3);                       // into the stage K-tile t - 1 occupied
+        const char* s = smem + (t & (SK_STAGES - 1)) * SK_STAGE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int sw = kk ? sw1 : sw0;
+            bf16x8_t af[2], wf[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) wf[j] = *(const bf16x8_t*)(s + w_off + j * 2048 + sw);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = *(const bf16x8_t*)(s + a_off + i * 2048 + sw);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (t == 0 && kk == 0)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    else
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+    // ---- epilogue: acc[i][j][e] = C[m0 + wm*32 + i*16 + fr][n0 + wn*32 + j*16 + fq*4 + e]; the arithmetic of gemm_epilogue, per element
+    const bool fold = (EPI < OV_EPI_BIAS_RESIDUAL) && g.colsum != nullptr;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int64_t m = m0 + wm * 32 + i * 16 + fr;
+        const int64_t mc = m < g.M ? m : g.M - 1;
+        float rmean = 0.f, rrstd = 1.f;
+        if (fold) {
+            const float2 st = *(const float2*)(g.rowstats + 2 * mc);
+            rmean = st.x; rrstd = st.y;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int nn = n0 + wn * 32 + j * 16 + fq * 4;
+            const bool ok = m < g.M && nn < g.N;           // N % 8 == 0 and nn % 4 == 0: the 4 columns are in or out together
+            const int nc = nn < g.N ? nn : g.N - 4;
+            f32x2_t b01 = {0.f, 0.f}, b23 = {0.f, 0.f};
+            if (g.bias != nullptr) {
+                const float4 b4 = *(const float4*)(g.bias + nc);
+                b01 = f32x2_t{b4.x, b4.y}; b23 = f32x2_t{b4.z, b4.w};
+            }
+            f32x2_t v01 = f32x2_t{acc[i][j][0], acc[i][j][1]};
+            f32x2_t v23 = f32x2_t{acc[i][j][2], acc[i][j][3]};
+            if (fold) {
+                const float4 s4 = *(const float4*)(g.colsum + nc);
+                const f32x2_t nm = {-rmean, -rmean}, rs = {rrstd, rrstd};
+                v01 = __builtin_elementwise_fma(f32x2_t{s4.x, s4.y}, nm, v01);
+                v23 = __builtin_elementwise_fma(f32x2_t{s4.z, s4.w}, nm, v23);
+                v01 = __builtin_elementwise_fma(v01, rs, b01);
+                v23 = __builtin_elementwise_fma(v23, rs, b23);
+            } else {
+                v01 += b01;
+                v23 += b23;
+            }
+            if (EPI == OV_EPI_BIAS_GELU_ERF) gelu_erf_f2x2(v01, v23);
+            if (EPI == OV_EPI_BIAS_GELU_TANH) { v01 = gelu_tanh_f2(v01); v23 = gelu_tanh_f2(v23); }
+            u32x2_t pk = {pack_bf16x2(v01[0], v01[1]), pack_bf16x2(v23[0], v23[1])};
+            if (EPI >= OV_EPI_BIAS_RESIDUAL) {
+                const int64_t rrow = g.resid_mod ? (mc % g.resid_mod) + g.resid_off : mc;
+                const u32x2_t rv = *(const u32x2_t*)(g.R + rrow * g.ldr + nc);
+                const u32x4_t o = epi_combine<EPI>(u32x4_t{pk[0], pk[1], pk[0], pk[1]}, u32x4_t{rv[0], rv[1], rv[0], rv[1]});
+                pk = u32x2_t{o[0], o[1]};
+            }
+            if (ok) {
+                const int64_t orow = g.out_group ? m + m / g.out_group + 1 : m;
+                *(u32x2_t*)(g.C + orow * g.ldc + nn) = pk;
+            }
+        }
+    }
+}
+
+int gemm_skinny_max_m() {      // rows up to which the skinny kernel takes over (OVHIP_GEMM_SKINNY_MAXM; 0 = never)
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("OVHIP_GEMM_SKINNY_MAXM"); v = e ? atoi(e) : 512; }
+    return v;
+}
+
 int num_cus() { return ov_num_cus(); }
 
 thread_local const float* g_colsum = nullptr;      // set by ov_gemm_ln around its call into ov_gemm
@@ -1237,11 +1378,11 @@ unsigned long long* g_stamps = nullptr;
 unsigned long long* g_wstamps = nullptr;
 int g_stamp_slots = 0;
 
-int gemm_variant() {       // 0 = persistent ping-pong (default), 1 = v1 two-stage, 2 = non-persistent ping-pong, 3 = four-wave prototype
-    static int v = -1;
+int gemm_variant() {       // 0 = default (persistent ping-pong; skinny kernel for small M), 1 = v1 two-stage, 2 = non-persistent ping-pong,
+    static int v = -1;     // 3 = four-wave prototype, 4 = skinny kernel for EVERY shape (tests: bitwise against the default)
     if (v < 0) {
         const char* e = getenv("OVHIP_GEMM_VARIANT");
-        v = (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 0;
+        v = (e && e[0] >= '0' && e[0] <= '4') ? e[0] - '0' : 0;
     }
     return v;
 }
@@ -1295,6 +1436,16 @@ int gemm_epi_prio() {
 template <int EPI>
 int launch(GemmArgs a, hipStream_t st) {
     int var = gemm_variant();
+    if (a.C2 == nullptr && (var == 4 || (var == 0 && a.M <= gemm_skinny_max_m()))) {
+        GemmArgs b = a;
+        b.tiles_m = (int)((a.M + SK_BM - 1) / SK_BM);
+        b.tiles_n = (a.N + SK_BN - 1) / SK_BN;
+        if ((int64_t)b.tiles_m * b.tiles_n > 0x7fffffffLL) return OV_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(gemm_bf16_skinny<EPI>, dim3((unsigned)(b.tiles_m * b.tiles_n)), dim3(256), 0, st, b);
+        OV_LAUNCH_CHECK();
+        return OV_OK;
+    }
+    if (var == 4) var = 0;
     const int nwg = a.tiles_m * a.tiles_n;
     // fewer tiles than CUs (pooled heads, the tower's tail images): persistence buys nothing, use the plain launch
     // the persistent kernel also wins on grids somewhat smaller than the chip (one tile per workgroup, but its epilogue starts
@@ -1346,7 +1497,11 @@ int launch(GemmArgs a, hipStream_t st) {
             constexpr int E = (EPI == OV_EPI_BIAS_GELU_ERF || EPI == OV_EPI_BIAS_GELU_TANH) ? EPI : OV_EPI_BIAS_GELU_ERF;
             hipLaunchKernelGGL((gemm_bf16_persist<E, false, true, false, true>), grid, blk, 0, st, a);
         } else if (CAN_FOLD && a.colsum != nullptr) {
-            hipLaunchKernelGGL((gemm_bf16_persist<EPI, CAN_FOLD, true, false>), grid, blk, 0, st, a);
+            // GELU with the LN fold (vision / text c_fc): OVHIP_GEMM_GELU_LDS=1 selects the LDS-transposed form (whole-line stores)
+            static int gelu_lds = -1;
+            if (gelu_lds < 0) { const char* e = getenv("OVHIP_GEMM_GELU_LDS"); gelu_lds = (e && e[0] == '1') ? 1 : 0; }
+            if (gelu_lds) hipLaunchKernelGGL((gemm_bf16_persist<EPI, CAN_FOLD, false, false>), grid, blk, 0, st, a);
+            else hipLaunchKernelGGL((gemm_bf16_persist<EPI, CAN_FOLD, true, false>), grid, blk, 0, st, a);
         } else if (EPI == OV_EPI_BIAS_RESIDUAL && mapped) {
             hipLaunchKernelGGL((gemm_bf16_persist<OV_EPI_BIAS_RESIDUAL, false, true, true>), grid, blk, 0, st, a);
         } else {

@@ -261,6 +261,12 @@ def test_batch_invariance_and_determinism(tiny):
     b = torch.cat([tiny.encode_image(img[:4]), tiny.encode_image(img[4:])])
     assert torch.equal(a, b)                                     # row results do not depend on batch composition
     assert torch.equal(a, tiny.encode_image(img))                # bitwise repeatable
+    # batch 1 (the script's operating point, ov-zero-shot-test.py:167-181: M = 101 rows -> the skinny small-M GEMM kernel) against the
+    # same image inside a batch of 9 (M = 909 rows -> the persistent 256 x 256 kernels): the kernels share the order of accumulation
+    assert torch.equal(tiny.encode_image(img[3:4]), a[3:4])
+    tok = synth.make_captions(9, seed=5).to(DEV)
+    t9 = tiny.encode_text(tok)
+    assert torch.equal(tiny.encode_text(tok[2:3]), t9[2:3]) and torch.equal(tiny.encode_text(tok[:4]), t9[:4])
 
 
 @pytest.mark.timeout(900)
@@ -281,6 +287,7 @@ def test_large14_224_features():
     big = synth.make_images(48, 224, seed=3).to(DEV).to(torch.bfloat16)
     fb = m.encode_image(big)
     assert torch.equal(fb[:7], m.encode_image(big[:7]))
+    assert torch.equal(fb[5:6], m.encode_image(big[5:6]))         # batch 1: M = 257 rows, the skinny kernel
     assert torch.isfinite(fb).all()
     # bitwise repeatability with several heads per persistent attention workgroup (48*16 heads > 256 CUs) and
     # persistent GEMM tiles: guards the LDS-DMA double-buffer hand-offs (a real race was caught this way)

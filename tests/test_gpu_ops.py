@@ -730,11 +730,12 @@ def test_gemm_tn_matches_transposed_operands(Mc, NI, NJ, chunk):
     assert torch.equal(got, ref2)
 
 
-@pytest.mark.parametrize("variant", ["1", "2", "3"])
+@pytest.mark.parametrize("variant", ["1", "2", "3", "4"])
 def test_gemm_kernel_variants_agree_bitwise_with_the_default(variant):
     """OVHIP_GEMM_VARIANT (read once per process, so each variant runs in a child process): the simple two-stage kernel (1), the
-    non-persistent ping-pong kernel (2) and the four-wave prototype (3) accumulate the same products in the same order and share the
-    epilogue arithmetic: every epilogue's output must equal the default persistent kernel's bit for bit, on ragged shapes too."""
+    non-persistent ping-pong kernel (2), the four-wave prototype (3) and the skinny small-M kernel forced onto every shape (4: by
+    default it serves M <= 512, the batch-1 path) accumulate the same products in the same order and share the epilogue arithmetic:
+    every epilogue's output must equal the default persistent kernel's bit for bit, on ragged shapes too."""
     import subprocess, sys, tempfile
     code = r"""
 import os, sys, torch
