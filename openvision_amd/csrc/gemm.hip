@@ -1362,9 +1362,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_skinny(const GemmArgs g) {
     }
 }
 
-int gemm_skinny_max_m() {      // rows up to which the skinny kernel takes over (OVHIP_GEMM_SKINNY_MAXM; 0 = never)
+// The skinny kernel takes over while the shape gives the 256 x 256 kernels at most this many tiles (OVHIP_GEMM_SKINNY_TILES; 0 =
+// never).  Measured crossover on the four L/14 block shapes (tools/dbg/skinny_cross.py): QKV / c_fc win with the skinny kernel up to
+// 60 / 80 big tiles (M = 1028) and lose at 108 / 144 (M = 2056), out_proj / c_proj win at 68 (M = 4112) and lose at 132 (M = 8224).
+int gemm_skinny_tiles() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("OVHIP_GEMM_SKINNY_MAXM"); v = e ? atoi(e) : 512; }
+    if (v < 0) { const char* e = getenv("OVHIP_GEMM_SKINNY_TILES"); v = e ? atoi(e) : 96; }
     return v;
 }
 
@@ -1436,7 +1439,7 @@ int gemm_epi_prio() {
 template <int EPI>
 int launch(GemmArgs a, hipStream_t st) {
     int var = gemm_variant();
-    if (a.C2 == nullptr && (var == 4 || (var == 0 && a.M <= gemm_skinny_max_m()))) {
+    if (a.C2 == nullptr && (var == 4 || (var == 0 && (int64_t)a.tiles_m * a.tiles_n <= gemm_skinny_tiles()))) {
         GemmArgs b = a;
         b.tiles_m = (int)((a.M + SK_BM - 1) / SK_BM);
         b.tiles_n = (a.N + SK_BN - 1) / SK_BN;

@@ -38,6 +38,15 @@ struct ov_tower {
     unsigned char* mask8;         // fp8 path: per layer, which of the four GEMMs take e4m3 operands (OV_FP8_QKV | _OUT | _FC | _PROJ)
 };
 
+// Row pitch (elements) of the workspace's `big` region (qkv / MLP hidden).  max(3 D, mlp_pad) is a power-of-two number of bytes for
+// the usual widths (L/14: 8 KiB), and the 256 rows of a GEMM operand piece then start 8 KiB apart: OVHIP_BIG_PAD elements (a multiple
+// of 64 = one 128-byte line) are added to the pitch to spread them over the memory channels.
+static inline int big_pitch(const ov_tower_cfg& c) {
+    static int pad = -1;
+    if (pad < 0) { const char* e = getenv("OVHIP_BIG_PAD"); pad = e ? atoi(e) : 0; if (pad < 0 || pad % 64) pad = 0; }
+    return (3 * c.width > c.mlp_pad ? 3 * c.width : c.mlp_pad) + pad;
+}
+
 namespace {
 // ---- optional in-situ kernel timing (HIP events on the caller's stream; off by default) -----------------
 struct ProfRec { int cls; hipEvent_t e0, e1; int64_t rows; };
@@ -267,7 +276,7 @@ extern "C" size_t ov_tower_workspace_bytes(const ov_tower* t, int B, int L) {
     if (!t || B <= 0 || L <= 0) return 0;
     const size_t M = (size_t)B * L;
     const int D = t->cfg.width;
-    size_t n = align_up(M * D * 2, 256) + align_up(M * (size_t)max_i(3 * D, t->cfg.mlp_pad) * 2, 256) + align_up(M * 8, 256);
+    size_t n = align_up(M * D * 2, 256) + align_up(M * (size_t)big_pitch(t->cfg) * 2, 256) + align_up(M * 8, 256);
     if (tower_fp8(t)) n += align_up(M * (size_t)max_i(D, t->cfg.mlp_pad), 256) + align_up(M * 4, 256);   // fp8 activations + row scales
     return n;
 }
@@ -278,7 +287,7 @@ int run_block(const ov_tower_cfg& c, const ov_block_weights& w, ov_bf16* x, ov_b
               int L, ov_stream_t stream, bool prof) {
     const int D = c.width, H = c.heads, hd = D / H;
     const int64_t M = (int64_t)B * L;
-    const int ldb = 3 * D > c.mlp_pad ? 3 * D : c.mlp_pad;      // row pitch of `big` (shared by qkv and the MLP hidden)
+    const int ldb = big_pitch(c);                               // row pitch of `big` (shared by qkv and the MLP hidden)
     const float scale = 1.0f / sqrtf((float)hd);
     const int gelu = c.gelu_tanh ? OV_EPI_BIAS_GELU_TANH : OV_EPI_BIAS_GELU_ERF;
     const int fc_cls = c.gelu_tanh ? OV_PROF_GEMM_FC_TANH : OV_PROF_GEMM_FC;
@@ -356,7 +365,7 @@ int run_block_fp8(const ov_tower_cfg& c, const ov_block_weights& w, const ov_blo
                   int L, ov_stream_t stream, bool prof) {
     const int D = c.width, H = c.heads, hd = D / H, F = c.mlp_pad;
     const int64_t M = (int64_t)B * L;
-    const int ldb = 3 * D > F ? 3 * D : F;
+    const int ldb = big_pitch(c);
     const float scale = 1.0f / sqrtf((float)hd);
     const int gelu = c.gelu_tanh ? OV_EPI_BIAS_GELU_TANH : OV_EPI_BIAS_GELU_ERF;
     const int fc_cls = c.gelu_tanh ? OV_PROF_GEMM_FC_TANH : OV_PROF_GEMM_FC;
@@ -437,7 +446,7 @@ extern "C" int ov_tower_forward(const ov_tower* t, ov_bf16* x, int B, int L, voi
     const ov_tower_cfg& c = t->cfg;
     const int D = c.width;
     const int64_t M = (int64_t)B * L;
-    const int ldb = 3 * D > c.mlp_pad ? 3 * D : c.mlp_pad;
+    const int ldb = big_pitch(c);
     ov_bf16* h = (ov_bf16*)workspace;
     ov_bf16* big = (ov_bf16*)((char*)workspace + align_up((size_t)M * D * 2, 256));
     float* stats = (float*)((char*)big + align_up((size_t)M * ldb * 2, 256));   // {mean, rstd} per row (LN fold)
