@@ -40,10 +40,10 @@ struct ov_tower {
 
 // Row pitch (elements) of the workspace's `big` region (qkv / MLP hidden).  max(3 D, mlp_pad) is a power-of-two number of bytes for
 // the usual widths (L/14: 8 KiB), and the 256 rows of a GEMM operand piece then start 8 KiB apart: OVHIP_BIG_PAD elements (a multiple
-// of 64 = one 128-byte line) are added to the pitch to spread them over the memory channels.
+// of 64 = one 128-byte line; default 64) are added to the pitch to spread them over the memory channels (L/14 step 45.09 -> 44.85 ms).
 static inline int big_pitch(const ov_tower_cfg& c) {
     static int pad = -1;
-    if (pad < 0) { const char* e = getenv("OVHIP_BIG_PAD"); pad = e ? atoi(e) : 0; if (pad < 0 || pad % 64) pad = 0; }
+    if (pad < 0) { const char* e = getenv("OVHIP_BIG_PAD"); pad = e ? atoi(e) : 64; if (pad < 0 || pad % 64) pad = 64; }
     return (3 * c.width > c.mlp_pad ? 3 * c.width : c.mlp_pad) + pad;
 }
 
