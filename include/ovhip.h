@@ -120,6 +120,17 @@ int ov_gemm_keep(const ov_bf16* A, int64_t lda, const ov_bf16* W, int64_t ldw, c
 /* rowstats[r] = {mean, rsqrt(var + eps)} of x[r, 0:D] (bf16 rows, fp32 two-pass statistics, biased variance). */
 int ov_rowstats(const ov_bf16* x, int64_t ldx, float* rowstats, int64_t rows, int D, float eps, ov_stream_t stream);
 
+/* The same statistics through partial sums (the LayerNorm of transformer.py:15-30 in front of the folded QKV / c_fc GEMMs, without a
+ * separate pass over the residual stream): parts[r][D / 32] = {sum, sum of squares} (fp32) of the bf16 values x[r, 32 g .. 32 g + 31], in
+ * ONE fixed association order -- ov_gemm_rowparts leaves exactly these numbers for its output rows (from its epilogue where the kernel
+ * can, by this pass otherwise: bitwise the same), ov_rowstats_finalize turns them into {mean, rsqrt(var + eps)} with var = E[x^2] -
+ * mean^2 (one pass; fp32).  D % 32 == 0. */
+int ov_rowparts(const ov_bf16* x, int64_t ldx, float* parts, int64_t rows, int D, ov_stream_t stream);
+int ov_rowstats_finalize(const float* parts, float* rowstats, int64_t rows, int D, float eps, ov_stream_t stream);
+/* ov_gemm(..., OV_EPI_BIAS_RESIDUAL, R, ldr, no row maps) that also writes parts[M][N / 32] of its OUTPUT rows (N % 32 == 0). */
+int ov_gemm_rowparts(const ov_bf16* A, int64_t lda, const ov_bf16* W, int64_t ldw, const float* bias, ov_bf16* C, int64_t ldc,
+                     int64_t M, int N, int K, const ov_bf16* R, int64_t ldr, float* parts, ov_stream_t stream);
+
 /* Non-causal, unmasked multi-head self-attention on a packed qkv activation.
  * qkv: [B*L, 3*H*hd] bf16 (q | k | v column blocks, heads contiguous inside each, ld = ld_qkv);
  * out: [B*L, H*hd] bf16 (heads merged, ld = ld_out).  scale multiplies q.k (hd^-0.5).

@@ -81,6 +81,10 @@ SIGNATURES = {
     "ov_gemm_keep": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int,
                              c_int, c_void_p]),
     "ov_rowstats": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_float, c_void_p]),
+    "ov_rowparts": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p]),
+    "ov_rowstats_finalize": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),
+    "ov_gemm_rowparts": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_int64,
+                                 c_void_p, c_void_p]),
     "ov_attention": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "ov_im2col_patches": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "ov_cls_rows": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

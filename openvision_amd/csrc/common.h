@@ -211,6 +211,51 @@ __device__ __forceinline__ u32x4_t epi_combine(u32x4_t o, u32x4_t r) {
     return out;
 }
 
+// The lane id, recomputed where it is needed (two VALU instructions) and opaque to CSE: as ONE value defined at kernel entry it is live
+// through every K-tile variant and epilogue, and in the kernels at the register limit (fp8 GEMM, persistent GEMM with row statistics) it was what got spilled: a scratch reload
+// inside the epilogue is a vector-memory operation the hand-counted vmcnt waits do not know about.
+__device__ __forceinline__ int fresh_lane() {
+    int l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(l));
+    return l;
+}
+
+// ---- row statistics in partial sums (round 3): {sum x, sum x^2} over every 32-column group of a row, computed on the bf16-ROUNDED
+// values with ONE sequence of operations wherever they are produced -- the persistent GEMM's residual epilogue, the skinny GEMM's, or
+// the stand-alone pass over x (ov_rowparts) -- so that a row's statistics are bitwise the same whichever kernel wrote the row:
+//   quad  (4 consecutive n = two packed dwords): two chained v_dot2c_f32_bf16 from 0 (sum: against {1, 1}; squares: against itself --
+//                                                 bf16 products are exact in fp32, the adds round as the instruction rounds them)
+//   octet (8 consecutive n)                     = quad(n 0-3) + quad(n 4-7)
+//   block (16 n = one MFMA fragment column)     = octet 0 + octet 1
+//   group (32 n)                                = block 0 + block 1
+// __fadd_rn: no contraction, no re-association.  The dot instructions are inline asm (one statement: the two accumulation chains
+// interleaved, the wait states a DOT result needs before an ordinary VALU read appended -- the assembler does not look inside asm).
+__device__ __forceinline__ void stat_quad(unsigned w0, unsigned w1, float& s, float& q) {
+    float ss = 0.f, qq = 0.f;
+    const unsigned ones = 0x3f803f80u;       // bf16 {1, 1}
+    asm("v_dot2c_f32_bf16 %0, %2, %4\n\tv_dot2c_f32_bf16 %1, %2, %2\n\tv_dot2c_f32_bf16 %0, %3, %4\n\tv_dot2c_f32_bf16 %1, %3, %3\n\ts_nop 2"
+        : "+v"(ss), "+v"(qq) : "v"(w0), "v"(w1), "v"(ones));
+    s = ss;
+    q = qq;
+}
+__device__ __forceinline__ void stat_octet(u32x4_t w, float& s, float& q) {
+    float s0, q0, s1, q1;
+    stat_quad(w[0], w[1], s0, q0);
+    stat_quad(w[2], w[3], s1, q1);
+    s = __fadd_rn(s0, s1);
+    q = __fadd_rn(q0, q1);
+}
+// x[lane] + x[lane ^ 32] in the order (lower half) + (upper half), in every lane
+__device__ __forceinline__ float add_halves_lo_first(float x) {
+    const u32x2_t t = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __fadd_rn(__uint_as_float(t[0]), __uint_as_float(t[1]));
+}
+// x[even 16-lane row] + x[odd 16-lane row] of each pair of rows, in that order, in every lane of the pair
+__device__ __forceinline__ float add_rowpair_even_first(float x) {
+    const u32x2_t t = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __fadd_rn(__uint_as_float(t[0]), __uint_as_float(t[1]));
+}
+
 // 16-byte output store with a compile-time cache policy: 0 = plain, 1 = sc1 (write-through; the line is not kept in the XCD's L2 --
 // MI355X_MICROARCH.md, store flavours), 2 = nt (streaming), 4 = sc0 sc1.  A tile's 128 KiB of output otherwise displace the W slice /
 // A panels the next K-tiles are about to be fetched from (32 CUs x 128 KiB = the whole 4 MiB L2 of an XCD per round of tiles).

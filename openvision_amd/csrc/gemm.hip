@@ -44,6 +44,8 @@ struct GemmArgs {
     ov_bf16* C2; int64_t ldc2;           // ov_gemm_keep: second output = the GELU epilogue's pre-activation (acc + bias), bf16
     float* psum;                         // gemm_bf16_pp_tn: [gridDim.y][M] column sums of P over the split's rows (NULL = off)
     int exp;                             // persistent kernel: experiment bits (OVHIP_GEMM_EXP; none defined at present)
+    float* rowpart;                      // residual epilogue (persistent direct form, skinny kernel): {sum, sum of squares} of every
+                                         // 32-column group of every OUTPUT row, [M][N / 32][2] fp32 (common.h: row statistics); NULL = off
 };
 
 template <int V> struct IntC { static constexpr int value = V; };
@@ -662,9 +664,24 @@ constexpr int SMEM_PERSIST = IMG_OFF + 8 * 2048;     // 152 KiB of the CU's 160 
 // `g.out_group ? m + m / g.out_group + 1 : m` and computes the software division on every store), and row pointers are one
 // 64-bit multiply per lane, stepped by whole rows, instead of one per store -- ~250 of the ~500 (bias) to ~1200 (residual) VALU
 // instructions of the epilogue were such address arithmetic.
-template <int EPI, bool FOLD, bool MAPPED, bool KEEP = false>
+template <int N> __device__ __forceinline__ void wait_vmcnt() {          // literal counts only (the hand-counted waits of the epilogues)
+    static_assert(N == 8 || N == 14 || N == 22 || N == 24 || N == 26 || N == 28, "add the literal");
+    if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (N == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+    else if (N == 22) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+    else if (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else if (N == 26) asm volatile("s_waitcnt vmcnt(26)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
+}
+
+// STATS (residual epilogue only): every pass also forms the row statistics' partial sums of its 16 rows x 64 columns (two 32-column
+// groups per wave: common.h) and leaves them in an LDS image of the tile; gemm_bf16_persist writes the image out behind the tile
+// barrier.  The next LayerNorm's row pass (a re-read of the whole residual stream, 1.5 ms of the L/14 step) shrinks to a pass over
+// these sums.
+template <int EPI, bool FOLD, bool MAPPED, bool KEEP = false, bool STATS = false>
 __device__ __forceinline__ void epilogue_stream(const GemmArgs& g, f32x4_t (&acc)[8][4], const char* prm,
-                                                int64_t m0, int n0, int wave, int lane, bool edge, unsigned long long* wst) {
+                                                int64_t m0, int n0, int wave, int lane, bool edge, unsigned long long* wst,
+                                                char* stats_lds = nullptr) {
     const int wm = wave >> 2, wn = wave & 3;
     const int fr = lane & 15, fq = lane >> 4;
     const int cb = (fq & 1) * 16 + (fq >> 1) * 8;                 // column of this lane's 16-byte chunk inside a 32-column pair
@@ -741,17 +758,30 @@ __device__ __forceinline__ void epilogue_stream(const GemmArgs& g, f32x4_t (&acc
             u32x4_t o = vo[i][h];
             if (EPI >= OV_EPI_BIAS_RESIDUAL) o = epi_combine<EPI>(o, rv[i][h]);
             if (m < (unsigned)g.M && (h ? ncol1 : ncol0)) store16<OVHIP_ST_DIRECT>(dst + h * 32, o);
+            if (STATS) {
+                // this lane's 8 consecutive columns -> octet; fq 0 | 2 | 1 | 3 hold octets 0 | 1 | 2 | 3 of the 32-column group
+                float s8, q8;
+                stat_octet(o, s8, q8);
+                s8 = add_rowpair_even_first(add_halves_lo_first(s8));       // (oct0 + oct1) + (oct2 + oct3)
+                q8 = add_rowpair_even_first(add_halves_lo_first(q8));
+                // into the tile's [256 rows][8 groups] fp32-pair image in LDS; the workgroup writes it out in 64-byte row pieces
+                // behind the tile barrier (16 scattered 8-byte stores per pass measured slower than the pass over x they replace)
+                if (fq == 0) *(float2*)(stats_lds + ((wm * 128 + i * 16 + fr) * 8 + wn * 2 + h) * 8) = make_float2(s8, q8);
+            }
         }
     };
     // vmcnt is counted by hand around the asm residual loads: `edge` tiles issue fewer than 2 stores per pass, so they
     // fall back to a full drain
-    auto wait_resid = [&](int i0, int i1, int younger) {
-        if (edge) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (younger == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+    auto pin_rows = [&](int i0, int i1) {            // names the rows' registers behind the wait: no consumer can be scheduled above it
 #pragma unroll
         for (int k = i0; k < i1; ++k) asm volatile("" : "+v"(rv[k][0]), "+v"(rv[k][1]));
     };
+#define OV_WAIT_RESID(I0, I1, YOUNGER)                                        \
+    do {                                                                      \
+        if (edge) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           \
+        else wait_vmcnt<(YOUNGER)>();                                         \
+        pin_rows(I0, I1);                                                     \
+    } while (0)
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         if (wm == 1 && g.epi_prio > 0 && i == g.epi_prio) __builtin_amdgcn_s_setprio(0);
@@ -804,14 +834,15 @@ __device__ __forceinline__ void epilogue_stream(const GemmArgs& g, f32x4_t (&acc
             // in flight behind the rows waited for: i == 3 -> after the second batch of loads at i == 4.  Stores start once every
             // load is out: at i == 4 the rows of passes 4-7 (8 loads) are younger than those of passes 0-3; later, per pass, the
             // remaining row loads plus the stores of all earlier passes = 14 every time
-            if (i == 4) { wait_resid(0, 4, 8); put(0); put(1); put(2); put(3); }
-            if (i >= 4) { wait_resid(i, i + 1, 14); put(i); }
+            if (i == 4) { OV_WAIT_RESID(0, 4, 8); put(0); put(1); put(2); put(3); }
+            if (i >= 4) { OV_WAIT_RESID(i, i + 1, 14); put(i); }
         } else {
             put(i);
         }
         if (wst != nullptr && lane == 0 && (i == 1 || i == 4)) wst[i == 1 ? 3 : 4] = __builtin_amdgcn_s_memtime();
     }
     if (wst != nullptr && lane == 0) wst[5] = __builtin_amdgcn_s_memtime();
+#undef OV_WAIT_RESID
 }
 
 // The same epilogue with the 16-byte stores made row-contiguous through a wave-local LDS image (8 lanes x 16 B = one 128-B line):
@@ -953,9 +984,9 @@ __device__ __forceinline__ void epilogue_stream_lds(const GemmArgs& g, f32x4_t (
 
 struct TileSrc { const ov_bf16* a0; const ov_bf16* a1; const ov_bf16* w0; const ov_bf16* w1; };   // per-lane staging sources
 
-template <int EPI, bool FOLD, bool DIRECT, bool MAPPED, bool KEEP = false>
+template <int EPI, bool FOLD, bool DIRECT, bool MAPPED, bool KEEP = false, bool STATS = false>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist(const GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) char smem[DIRECT ? IMG_OFF : SMEM_PERSIST];
+    __shared__ __attribute__((aligned(16))) char smem[DIRECT ? IMG_OFF + (STATS ? 256 * 64 : 0) : SMEM_PERSIST];   // STATS: + the tile's statistics image
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1018,6 +1049,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist(const GemmArgs 
         s2 = grouped ? qs / rad1 : 0;
     }
     auto set_tile = [&](TileSrc& ts, int64_t& mm, int& nn) {      // sets up the tile the counter points at, then steps the counter
+        // the lane's staging row / chunk, rebuilt per tile from an opaque lane id: as loop invariants hipcc kept the 64-bit per-lane
+        // offsets (row * ld + chunk) live through the whole tile loop -- and spilled them in the variant with row statistics
+        const int tid_f = wave * 64 + fresh_lane();
+        const int srow = tid_f >> 2;
+        const int schunk = (tid_f & 3) ^ swz4(srow);
         const int tm = p0 + d1, tn = d2 * rad0 + d0;
         d0 += s0;
         if (d0 >= rad0) { d0 -= rad0; ++d1; }
@@ -1208,15 +1244,33 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist(const GemmArgs 
         const bool edge = (m0 + BM > g.M) || (n0 + BN > g.N);      // an edge tile issues fewer than 16 stores per wave
         if (wst != nullptr && lane == 0) wst[1] = __builtin_amdgcn_s_memtime();
         if (g.epi_prio && wm == 1) __builtin_amdgcn_s_setprio(1);
-        if (DIRECT) epilogue_stream<EPI, FOLD, MAPPED, KEEP>(g, acc, smem + PRM_OFF + pslot * 4096, m0, n0, wave, lane, edge, wst);
+        if (DIRECT) epilogue_stream<EPI, FOLD, MAPPED, KEEP, STATS>(g, acc, smem + PRM_OFF + pslot * 4096, m0, n0, wave, lane, edge, wst, smem + IMG_OFF);
         else epilogue_stream_lds<EPI, FOLD, MAPPED>(g, acc, smem + IMG_OFF + wave * 2048, smem + PRM_OFF + pslot * 4096, m0, n0, wave, lane, edge, wst);
         if (g.epi_prio && wm == 1) __builtin_amdgcn_s_setprio(0);
         stamp(3);
         ++titer;
-        if (!has_next) break;
+        auto flush_stats = [&]() {
+            // the tile's statistics image -> rowpart: wave w takes rows 32 w .. 32 w + 31, a lane one 16-byte quarter (two groups) of a
+            // row's 64 bytes: 2 stores of 16 rows x 64 contiguous bytes.  (They sit behind the tile's output stores in the in-order
+            // queue: K-tile 0's vmcnt(16) then retires two of those early -- harmless; an edge tile makes the next wait strict anyway.)
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int ln = fresh_lane();            // (not a loop invariant of the tile loop: see fresh_lane)
+                const int row = wave * 32 + it * 16 + (ln >> 2), qd = ln & 3;
+                const u32x4_t v = *(const u32x4_t*)(smem + IMG_OFF + row * 64 + qd * 16);
+                const int64_t m = m0 + row;
+                const int grp = (n0 >> 5) + qd * 2;
+                if (m < g.M && grp * 32 < g.N) *(u32x4_t*)(g.rowpart + (m * (g.N >> 5) + grp) * 2) = v;
+            }
+        };
+        if (!has_next) {
+            if (STATS) { __builtin_amdgcn_s_barrier(); flush_stats(); }
+            break;
+        }
         strict = edge;
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();                               // next K-tile 0 visible to all
+        if (STATS) flush_stats();
         if (wst != nullptr && lane == 0) wst[6] = __builtin_amdgcn_s_memtime();
         if (wm == 1) __builtin_amdgcn_s_barrier();                  // re-stagger
         cb ^= STAGE_BYTES;
@@ -1322,6 +1376,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_skinny(const GemmArgs g) {
             const float2 st = *(const float2*)(g.rowstats + 2 * mc);
             rmean = st.x; rrstd = st.y;
         }
+        float gs = 0.f, gq = 0.f;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int nn = n0 + wn * 32 + j * 16 + fq * 4;
@@ -1358,6 +1413,21 @@ __global__ __launch_bounds__(256) void gemm_bf16_skinny(const GemmArgs g) {
                 const int64_t orow = g.out_group ? m + m / g.out_group + 1 : m;
                 *(u32x2_t*)(g.C + orow * g.ldc + nn) = pk;
             }
+            if (EPI == OV_EPI_BIAS_RESIDUAL && g.rowpart != nullptr) {      // wave-uniform
+                // the lane's quad (n fq*4 .. +3 of block j) -> octets (16-lane rows 0+1, 2+3) -> block (halves) -> group = block 0 + block 1
+                float sb, qb;
+                stat_quad(pk[0], pk[1], sb, qb);
+                sb = add_halves_lo_first(add_rowpair_even_first(sb));
+                qb = add_halves_lo_first(add_rowpair_even_first(qb));
+                if (j == 0) { gs = sb; gq = qb; }
+                else {
+                    gs = __fadd_rn(gs, sb);
+                    gq = __fadd_rn(gq, qb);
+                    const int nb = n0 + wn * 32;                             // this wave's 32-column group
+                    if (fq == 0 && m < g.M && nb < g.N)
+                        *(float2*)(g.rowpart + (m * (g.N >> 5) + (nb >> 5)) * 2) = make_float2(gs, gq);
+                }
+            }
         }
     }
 }
@@ -1377,6 +1447,7 @@ thread_local const float* g_colsum = nullptr;      // set by ov_gemm_ln around i
 thread_local const float* g_rowstats = nullptr;
 thread_local ov_bf16* g_keep = nullptr;            // set by ov_gemm_keep around its call into ov_gemm
 thread_local int64_t g_ldkeep = 0;
+thread_local float* g_rowpart = nullptr;           // set by ov_gemm_rowparts around its call into ov_gemm
 unsigned long long* g_stamps = nullptr;
 unsigned long long* g_wstamps = nullptr;
 int g_stamp_slots = 0;
@@ -1444,11 +1515,15 @@ int launch(GemmArgs a, hipStream_t st) {
         b.tiles_m = (int)((a.M + SK_BM - 1) / SK_BM);
         b.tiles_n = (a.N + SK_BN - 1) / SK_BN;
         if ((int64_t)b.tiles_m * b.tiles_n > 0x7fffffffLL) return OV_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL(gemm_bf16_skinny<EPI>, dim3((unsigned)(b.tiles_m * b.tiles_n)), dim3(256), 0, st, b);
+        hipLaunchKernelGGL(gemm_bf16_skinny<EPI>, dim3((unsigned)(b.tiles_m * b.tiles_n)), dim3(256), 0, st, b);     // (writes a.rowpart itself)
         OV_LAUNCH_CHECK();
         return OV_OK;
     }
     if (var == 4) var = 0;
+    // row-statistic partial sums: fused into the persistent kernel's direct residual epilogue; every other kernel is followed by the
+    // stand-alone pass over its output (the same arithmetic, common.h: bitwise the same sums)
+    float* const rowpart = a.rowpart;
+    bool stats_fused = false;
     const int nwg = a.tiles_m * a.tiles_n;
     // fewer tiles than CUs (pooled heads, the tower's tail images): persistence buys nothing, use the plain launch
     // the persistent kernel also wins on grids somewhat smaller than the chip (one tile per workgroup, but its epilogue starts
@@ -1503,15 +1578,20 @@ int launch(GemmArgs a, hipStream_t st) {
             // GELU with the LN fold (vision / text c_fc): OVHIP_GEMM_GELU_LDS=1 selects the LDS-transposed form (whole-line stores)
             static int gelu_lds = -1;
             if (gelu_lds < 0) { const char* e = getenv("OVHIP_GEMM_GELU_LDS"); gelu_lds = (e && e[0] == '1') ? 1 : 0; }
-            if (gelu_lds) hipLaunchKernelGGL((gemm_bf16_persist<EPI, CAN_FOLD, false, false>), grid, blk, 0, st, a);
-            else hipLaunchKernelGGL((gemm_bf16_persist<EPI, CAN_FOLD, true, false>), grid, blk, 0, st, a);
+            constexpr int EF = CAN_FOLD ? EPI : OV_EPI_BIAS_GELU_ERF;      // (the residual epilogues never come here: not instantiated)
+            if (gelu_lds) hipLaunchKernelGGL((gemm_bf16_persist<EF, true, false, false>), grid, blk, 0, st, a);
+            else hipLaunchKernelGGL((gemm_bf16_persist<EF, true, true, false>), grid, blk, 0, st, a);
         } else if (EPI == OV_EPI_BIAS_RESIDUAL && mapped) {
             hipLaunchKernelGGL((gemm_bf16_persist<OV_EPI_BIAS_RESIDUAL, false, true, true>), grid, blk, 0, st, a);
+        } else if (EPI == OV_EPI_BIAS_RESIDUAL && rowpart != nullptr) {
+            hipLaunchKernelGGL((gemm_bf16_persist<OV_EPI_BIAS_RESIDUAL, false, true, false, false, true>), grid, blk, 0, st, a);
+            stats_fused = true;
         } else {
             hipLaunchKernelGGL((gemm_bf16_persist<EPI, false, true, false>), grid, blk, 0, st, a);
         }
     }
     OV_LAUNCH_CHECK();
+    if (rowpart != nullptr && !stats_fused) return ov_rowparts(a.C, a.ldc, rowpart, a.M, a.N, (ov_stream_t)st);
     return OV_OK;
 }
 
@@ -1531,12 +1611,13 @@ extern "C" int ov_gemm(const ov_bf16* A, int64_t lda, const ov_bf16* W, int64_t 
     }
     if (epilogue > OV_EPI_BIAS_RESIDUAL && (out_group || resid_mod)) return OV_ERR_UNSUPPORTED;      // row maps: bias / residual only
     if (out_group < 0 || resid_mod < 0 || resid_off < 0) return OV_ERR_INVALID;
+    if (g_rowpart != nullptr && (epilogue != OV_EPI_BIAS_RESIDUAL || out_group || resid_mod || N % 32)) return OV_ERR_UNSUPPORTED;
     const int64_t tiles_m = (M + BM - 1) / BM;
     const int64_t tiles_n = (N + BN - 1) / BN;
     if (tiles_m * tiles_n > 0x7fffffffLL || M > 0x7fff0000LL) return OV_ERR_UNSUPPORTED;    // 32-bit row indices in the kernels
     GemmArgs a{A, W, bias, C, R, lda, ldw, ldc, ldr, M, N, K, (int)tiles_m, (int)tiles_n,
                out_group, resid_mod, resid_off, g_colsum, g_rowstats, g_stamps, g_stamp_slots, g_wstamps, gemm_ngroup((int)tiles_m, (int)tiles_n, K), 0, 0, 0,
-               gemm_stagger(K), gemm_stagger_classes(), gemm_epi_prio(), g_keep, g_ldkeep, nullptr, gemm_exp()};
+               gemm_stagger(K), gemm_stagger_classes(), gemm_epi_prio(), g_keep, g_ldkeep, nullptr, gemm_exp(), g_rowpart};
     hipStream_t st = (hipStream_t)stream;
     switch (epilogue) {
         case OV_EPI_BIAS: return launch<OV_EPI_BIAS>(a, st);
@@ -1558,6 +1639,18 @@ extern "C" int ov_gemm_keep(const ov_bf16* A, int64_t lda, const ov_bf16* W, int
     g_keep = C2; g_ldkeep = ldc2;
     const int rc = ov_gemm(A, lda, W, ldw, bias, C, ldc, M, N, K, epilogue, nullptr, 0, 0, 0, 0, stream);
     g_keep = nullptr; g_ldkeep = 0;
+    return rc;
+}
+
+// ov_gemm with the residual epilogue that also leaves the row statistics' partial sums of its OUTPUT: rowparts[m][N / 32] = {sum, sum
+// of squares} of the bf16 values C[m][32 g .. 32 g + 31] (fp32, fixed association: common.h) -- what ov_rowstats_finalize turns into
+// the next LayerNorm's {mean, rstd} without re-reading the residual stream.  N % 32 == 0, no row maps.
+extern "C" int ov_gemm_rowparts(const ov_bf16* A, int64_t lda, const ov_bf16* W, int64_t ldw, const float* bias, ov_bf16* C, int64_t ldc,
+                                int64_t M, int N, int K, const ov_bf16* R, int64_t ldr, float* rowparts, ov_stream_t stream) {
+    if (!rowparts || ((uintptr_t)rowparts & 7)) return OV_ERR_INVALID;
+    g_rowpart = rowparts;
+    const int rc = ov_gemm(A, lda, W, ldw, bias, C, ldc, M, N, K, OV_EPI_BIAS_RESIDUAL, R, ldr, 0, 0, 0, stream);
+    g_rowpart = nullptr;
     return rc;
 }
 

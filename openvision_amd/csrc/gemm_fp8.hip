@@ -48,15 +48,6 @@ struct Fp8Args {
 
 template <int V> struct IntC { static constexpr int value = V; };
 
-// The lane id, recomputed where it is needed (two VALU instructions) and opaque to CSE: as ONE value defined at kernel entry it is live
-// through every K-tile variant and epilogue, and in this kernel -- at the register limit -- it was what got spilled: a scratch reload
-// inside the epilogue is a vector-memory operation the hand-counted vmcnt waits do not know about.
-__device__ __forceinline__ int fresh_lane() {
-    int l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    asm volatile("" : "+v"(l));
-    return l;
-}
-
 // Maximum over the wave without index registers (DPP patterns + the two permlane swaps): __shfl_xor's six bpermute indices are
 // loop invariants of the whole kernel -- hipcc hoisted them to the kernel entry and spilled all six here.
 __device__ __forceinline__ float wave_max_noidx(float v) {

@@ -170,6 +170,73 @@ extern "C" int ov_layernorm(const void* x, int x_dtype, int64_t ldx, const float
     return launch_ln<16>(x, x_dtype, ldx, gamma, beta, y, y_dtype, ldy, rows, D, eps, st);
 }
 
+namespace {
+// Row statistics through partial sums (common.h): one thread per (row, 32-column group) reads 64 bytes and applies the fixed tree.
+__global__ __launch_bounds__(256) void rowparts_kernel(const ov_bf16* __restrict__ x, int64_t ldx, float* __restrict__ parts, int64_t rows, int G) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * G) return;
+    const int64_t row = idx / G;
+    const int g = (int)(idx - row * G);
+    const u32x4_t* p = (const u32x4_t*)(x + row * ldx + g * 32);
+    float s[4], q[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) stat_octet(p[o], s[o], q[o]);
+    const float sg = __fadd_rn(__fadd_rn(s[0], s[1]), __fadd_rn(s[2], s[3]));       // block 0 + block 1
+    const float qg = __fadd_rn(__fadd_rn(q[0], q[1]), __fadd_rn(q[2], q[3]));
+    *(float2*)(parts + idx * 2) = make_float2(sg, qg);
+}
+// {mean, rstd} of a row from its G partial sums: mean = S / D, var = Q / D - mean^2 (clamped at 0).  One pass instead of
+// rowstats_rows' two: fp32 sums of D <= 8192 bf16 values carry ~1e-7 relative error, so var is good to ~1e-7 (1 + mean^2 / var)
+// relative -- the LayerNorm inputs here have |mean| of the order of their standard deviation or below.  Eight lanes per row (a row's
+// G float2 are contiguous: coalesced 8-byte reads), each adds its groups g = k, k + 8, ... in that order, then a fixed xor tree over
+// the eight lanes (the same for every row, whatever wrote the sums).
+__global__ __launch_bounds__(256) void rowstats_finalize_kernel(const float* __restrict__ parts, float* __restrict__ st, int64_t rows, int G, float invD, float eps) {
+    const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3;
+    const int k = threadIdx.x & 7;
+    float S = 0.f, Q = 0.f;
+    if (row < rows) {
+        const float2* p = (const float2*)(parts + row * G * 2);
+        for (int g = k; g < G; g += 8) {
+            const float2 v = p[g];
+            S = __fadd_rn(S, v.x);
+            Q = __fadd_rn(Q, v.y);
+        }
+    }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+        S = __fadd_rn(S, __shfl_xor(S, o, 64));
+        Q = __fadd_rn(Q, __shfl_xor(Q, o, 64));
+    }
+    if (row < rows && k == 0) {
+        const float mean = __fmul_rn(S, invD);
+        const float var = fmaxf(__fsub_rn(__fmul_rn(Q, invD), __fmul_rn(mean, mean)), 0.f);
+        *(float2*)(st + 2 * row) = make_float2(mean, rsqrtf(var + eps));
+    }
+}
+}  // namespace
+
+extern "C" int ov_rowparts(const ov_bf16* x, int64_t ldx, float* parts, int64_t rows, int D, ov_stream_t stream) {
+    if (!x || !parts || rows <= 0 || D <= 0) return OV_ERR_INVALID;
+    if (D % 32 || ldx % 8 || ldx < D) return OV_ERR_UNSUPPORTED;
+    if (((uintptr_t)x & 15) || ((uintptr_t)parts & 7)) return OV_ERR_INVALID;
+    const int G = D / 32;
+    const int64_t n = rows * G;
+    if ((n + 255) / 256 > 0x7fffffffLL) return OV_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(rowparts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, parts, rows, G);
+    OV_LAUNCH_CHECK();
+    return OV_OK;
+}
+
+extern "C" int ov_rowstats_finalize(const float* parts, float* rowstats, int64_t rows, int D, float eps, ov_stream_t stream) {
+    if (!parts || !rowstats || rows <= 0 || D <= 0) return OV_ERR_INVALID;
+    if (D % 32 || D > 8192) return OV_ERR_UNSUPPORTED;
+    if (((uintptr_t)parts & 7) || ((uintptr_t)rowstats & 7)) return OV_ERR_INVALID;
+    hipLaunchKernelGGL(rowstats_finalize_kernel, dim3((unsigned)((rows * 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, parts, rowstats, rows,
+                       D / 32, 1.0f / (float)D, eps);
+    OV_LAUNCH_CHECK();
+    return OV_OK;
+}
+
 extern "C" int ov_rowstats(const ov_bf16* x, int64_t ldx, float* rowstats, int64_t rows, int D, float eps, ov_stream_t stream) {
     if (!x || !rowstats || rows <= 0 || D <= 0) return OV_ERR_INVALID;
     if (D % 8 || D > 8192 || ldx % 8 || ldx < D) return OV_ERR_UNSUPPORTED;

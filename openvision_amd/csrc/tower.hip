@@ -47,6 +47,17 @@ static inline int big_pitch(const ov_tower_cfg& c) {
     return (3 * c.width > c.mlp_pad ? 3 * c.width : c.mlp_pad) + pad;
 }
 
+// OVHIP_ROWPARTS=1: LayerNorm row statistics from the residual GEMMs' epilogues (ov_gemm_rowparts + ov_rowstats_finalize) instead of a
+// pass over the residual stream in front of every folded GEMM.  OFF by default: on the L/14 step the row passes shrink from 1.61 to
+// 0.59 ms and the two residual GEMM classes grow by 0.57 ms, but the step moves by 0.1 ms only (44.58 against 44.66 ms, alternating
+// runs) -- the memory-bound row passes were pauses in which the power-bound chip recovered clock for the next GEMM -- and the default
+// keeps the two-pass statistics.
+static inline bool use_rowparts() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("OVHIP_ROWPARTS"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v != 0;
+}
+
 namespace {
 // ---- optional in-situ kernel timing (HIP events on the caller's stream; off by default) -----------------
 struct ProfRec { int cls; hipEvent_t e0, e1; int64_t rows; };
@@ -276,15 +287,18 @@ extern "C" size_t ov_tower_workspace_bytes(const ov_tower* t, int B, int L) {
     if (!t || B <= 0 || L <= 0) return 0;
     const size_t M = (size_t)B * L;
     const int D = t->cfg.width;
-    size_t n = align_up(M * D * 2, 256) + align_up(M * (size_t)big_pitch(t->cfg) * 2, 256) + align_up(M * 8, 256);
+    size_t n = align_up(M * D * 2, 256) + align_up(M * (size_t)big_pitch(t->cfg) * 2, 256) + align_up(M * 8, 256) +
+               align_up(M * (size_t)(D / 32) * 8, 256);            // h | big | row statistics | their partial sums (last)
     if (tower_fp8(t)) n += align_up(M * (size_t)max_i(D, t->cfg.mlp_pad), 256) + align_up(M * 4, 256);   // fp8 activations + row scales
     return n;
 }
 
 namespace {
 // One ResidualAttentionBlock on rows [0, B*L) of x (in place).  `prof` = record in-situ timings for these launches.
-int run_block(const ov_tower_cfg& c, const ov_block_weights& w, ov_bf16* x, ov_bf16* h, ov_bf16* big, float* stats, int B,
-              int L, ov_stream_t stream, bool prof) {
+// `parts` (or NULL): partial sums of x's row statistics (ov_rowparts layout).  parts_in: they describe x on entry (left by the previous
+// block's c_proj); they always describe x on exit.
+int run_block(const ov_tower_cfg& c, const ov_block_weights& w, ov_bf16* x, ov_bf16* h, ov_bf16* big, float* stats, float* parts,
+              bool parts_in, int B, int L, ov_stream_t stream, bool prof) {
     const int D = c.width, H = c.heads, hd = D / H;
     const int64_t M = (int64_t)B * L;
     const int ldb = big_pitch(c);                               // row pitch of `big` (shared by qkv and the MLP hidden)
@@ -299,24 +313,29 @@ int run_block(const ov_tower_cfg& c, const ov_block_weights& w, ov_bf16* x, ov_b
         else rc = (call);                                            \
         if (rc) return rc;                                           \
     } while (0)
+    const bool rp = fold && parts != nullptr;                   // statistics ride on the residual GEMMs' epilogues
     if (fold) {
-        OV_STEP(OV_PROF_LN, ov_rowstats(x, D, stats, M, D, c.ln_eps, stream));
+        if (rp && parts_in) OV_STEP(OV_PROF_LN, ov_rowstats_finalize(parts, stats, M, D, c.ln_eps, stream));
+        else OV_STEP(OV_PROF_LN, ov_rowstats(x, D, stats, M, D, c.ln_eps, stream));
         OV_STEP(OV_PROF_GEMM_QKV, ov_gemm_ln(x, D, w.qkv_w, D, w.qkv_b, w.qkv_colsum, stats, big, ldb, M, 3 * D, D, OV_EPI_BIAS, stream));
     } else {
         OV_STEP(OV_PROF_LN, ov_layernorm(x, OV_BF16, D, w.ln1_w, w.ln1_b, h, OV_BF16, D, M, D, c.ln_eps, stream));
         OV_STEP(OV_PROF_GEMM_QKV, ov_gemm(h, D, w.qkv_w, D, w.qkv_b, big, ldb, M, 3 * D, D, OV_EPI_BIAS, nullptr, 0, 0, 0, 0, stream));
     }
     OV_STEP(OV_PROF_ATTN, ov_attention(big, ldb, h, D, B, L, H, hd, scale, stream));
-    OV_STEP(OV_PROF_GEMM_OUT, ov_gemm(h, D, w.out_w, D, w.out_b, x, D, M, D, D, OV_EPI_BIAS_RESIDUAL, x, D, 0, 0, 0, stream));
+    if (rp) OV_STEP(OV_PROF_GEMM_OUT, ov_gemm_rowparts(h, D, w.out_w, D, w.out_b, x, D, M, D, D, x, D, parts, stream));
+    else OV_STEP(OV_PROF_GEMM_OUT, ov_gemm(h, D, w.out_w, D, w.out_b, x, D, M, D, D, OV_EPI_BIAS_RESIDUAL, x, D, 0, 0, 0, stream));
     if (fold) {
-        OV_STEP(OV_PROF_LN, ov_rowstats(x, D, stats, M, D, c.ln_eps, stream));
+        if (rp) OV_STEP(OV_PROF_LN, ov_rowstats_finalize(parts, stats, M, D, c.ln_eps, stream));
+        else OV_STEP(OV_PROF_LN, ov_rowstats(x, D, stats, M, D, c.ln_eps, stream));
         OV_STEP(fc_cls, ov_gemm_ln(x, D, w.fc_w, D, w.fc_b, w.fc_colsum, stats, big, ldb, M, c.mlp_pad, D, gelu, stream));
     } else {
         OV_STEP(OV_PROF_LN, ov_layernorm(x, OV_BF16, D, w.ln2_w, w.ln2_b, h, OV_BF16, D, M, D, c.ln_eps, stream));
         OV_STEP(fc_cls, ov_gemm(h, D, w.fc_w, D, w.fc_b, big, ldb, M, c.mlp_pad, D, gelu, nullptr, 0, 0, 0, 0, stream));
     }
-    OV_STEP(OV_PROF_GEMM_PROJ, ov_gemm(big, ldb, w.proj_w, c.mlp_pad, w.proj_b, x, D, M, D, c.mlp_pad, OV_EPI_BIAS_RESIDUAL, x,
-                                       D, 0, 0, 0, stream));
+    if (rp) OV_STEP(OV_PROF_GEMM_PROJ, ov_gemm_rowparts(big, ldb, w.proj_w, c.mlp_pad, w.proj_b, x, D, M, D, c.mlp_pad, x, D, parts, stream));
+    else OV_STEP(OV_PROF_GEMM_PROJ, ov_gemm(big, ldb, w.proj_w, c.mlp_pad, w.proj_b, x, D, M, D, c.mlp_pad, OV_EPI_BIAS_RESIDUAL, x,
+                                            D, 0, 0, 0, stream));
 #undef OV_STEP
     return OV_OK;
 }
@@ -471,6 +490,8 @@ extern "C" int ov_tower_forward(const ov_tower* t, ov_bf16* x, int B, int L, voi
     int rc = OV_OK;
     if (fp8 && t->h_amax && t->h_mode == 2)            // delayed scaling: last forward's maxima become this forward's scales
         rc = ov_amax_roll(t->h_amax, t->h_amax + 2 * c.layers, 2 * c.layers, stream);
+    const int G = D / 32;
+    float* parts = use_rowparts() && !fp8 ? (float*)((char*)workspace + ov_tower_workspace_bytes(t, B, L) - align_up((size_t)M * G * 8, 256)) : nullptr;
     const int qw = D > c.mlp_pad ? D : c.mlp_pad;                 // row pitch reserved per token in the fp8 activation buffer
     unsigned char* q8 = (unsigned char*)stats + align_up((size_t)M * 8, 256);
     float* qs = (float*)(q8 + align_up((size_t)M * qw, 256));
@@ -481,12 +502,12 @@ extern "C" int ov_tower_forward(const ov_tower* t, ov_bf16* x, int B, int L, voi
         float* an = t->h_amax ? t->h_amax + 3 * c.layers + i : nullptr;
         const int hm = t->h_amax ? t->h_mode : 0;
         rc = fp8 ? run_block_fp8(c, t->blocks[i], t->fp8[i], t->mask8[i], x, h, big, stats, q8, qs, ha, aa, hn, an, hm, Bm, L, stream, true)
-                 : run_block(c, t->blocks[i], x, h, big, stats, Bm, L, stream, true);
+                 : run_block(c, t->blocks[i], x, h, big, stats, parts, i > 0, Bm, L, stream, true);
         if (rc == OV_OK && nt > 0) {
             rc = fp8 ? run_block_fp8(c, t->blocks[i], t->fp8[i], t->mask8[i], x + off * D, h + off * D, big + off * ldb, stats + 2 * off,
                                      q8 + off * qw, qs + off, ha, aa, hn, an, hm, nt, L, (ov_stream_t)tc->stream, false)
-                     : run_block(c, t->blocks[i], x + off * D, h + off * D, big + off * ldb, stats + 2 * off, nt, L,
-                                 (ov_stream_t)tc->stream, false);
+                     : run_block(c, t->blocks[i], x + off * D, h + off * D, big + off * ldb, stats + 2 * off,
+                                 parts ? parts + 2 * off * G : nullptr, i > 0, nt, L, (ov_stream_t)tc->stream, false);
         }
     }
     if (nt > 0) {

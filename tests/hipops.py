@@ -72,6 +72,34 @@ def rowstats(x, eps=1e-6):
     return st
 
 
+def rowparts(x):
+    """Partial sums of the row statistics: [rows, D / 32, 2] fp32 (ov_rowparts)."""
+    lib = _lib.load()
+    parts = torch.empty(x.shape[0], x.shape[1] // 32, 2, dtype=torch.float32, device=x.device)
+    check(lib.ov_rowparts(ptr(x), x.stride(0), ptr(parts), x.shape[0], x.shape[1], stream_ptr()))
+    return parts
+
+
+def rowstats_finalize(parts, eps=1e-6):
+    lib = _lib.load()
+    st = torch.empty(parts.shape[0], 2, dtype=torch.float32, device=parts.device)
+    check(lib.ov_rowstats_finalize(ptr(parts), ptr(st), parts.shape[0], parts.shape[1] * 32, eps, stream_ptr()))
+    return st
+
+
+def gemm_rowparts(a, w, bias, resid, out=None):
+    """Residual GEMM that also leaves the partial sums of its output rows (ov_gemm_rowparts)."""
+    lib = _lib.load()
+    m, k = a.shape
+    n = w.shape[0]
+    if out is None:
+        out = torch.zeros(m, n, dtype=torch.bfloat16, device=a.device)
+    parts = torch.full((m, n // 32, 2), float("nan"), dtype=torch.float32, device=a.device)
+    check(lib.ov_gemm_rowparts(ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(out), out.stride(0), m, n, k,
+                               ptr(resid), resid.stride(0), ptr(parts), stream_ptr()))
+    return out, parts
+
+
 def gemm_ln(x, wg, cvec, colsum, stats, epi=0):
     lib = _lib.load()
     m, k = x.shape

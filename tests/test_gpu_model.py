@@ -122,6 +122,40 @@ def test_tiny_testcat_table_topk(tiny_sharp):
     np.testing.assert_allclose(probs.numpy(), g["probs"], atol=0.05)
 
 
+def test_row_statistics_from_the_residual_epilogues_opt_in():
+    """OVHIP_ROWPARTS=1 (read once per process: a child process): the LayerNorm statistics in front of the folded QKV / c_fc GEMMs come
+    from the residual GEMMs' epilogues (ov_gemm_rowparts -> ov_rowstats_finalize; one-pass variance) instead of ov_rowstats' two passes
+    over the residual stream.  Same parity bar as the default path (L/14 golden, fp32 reference, 1e-3 cosine on both weight sets'
+    image embeddings) and rows stay bitwise batch-invariant across the three producers of the sums (skinny kernel at batch 1,
+    stand-alone pass behind the non-persistent kernel at batch 40, persistent kernel's epilogue at batch 256)."""
+    import subprocess
+    import sys
+    code = r"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.environ["OV_ROOT"]); sys.path.insert(0, os.path.join(os.environ["OV_ROOT"], "tests"))
+from openvision_amd import preset, synth
+from openvision_amd.model import create_model
+cfg = preset("vit-large-patch14-224")
+for variant, gname in (("v1", "large14_224.npz"), ("sharp", "large14_224_sharp.npz")):
+    g = np.load(os.path.join(os.environ["OV_ROOT"], "tests", "golden", gname))
+    m = create_model(cfg, device="cuda:0", state_dict=synth.make_state_dict(cfg, 0, variant))
+    img = torch.from_numpy(g["images"].astype(np.float32)).cuda()
+    f = m.encode_image(img).cpu()
+    c = (1 - torch.nn.functional.cosine_similarity(f, torch.from_numpy(g["image_features"].astype(np.float32)))).max().item()
+    assert c < 1e-3, (variant, c)
+    if variant == "sharp":
+        big = synth.make_structured_images(256, 224, seed=9).cuda().to(torch.bfloat16)
+        fb = m.encode_image(big)
+        assert torch.equal(fb[7:8], m.encode_image(big[7:8])), "batch 1 vs 256"
+        assert torch.equal(fb[:40], m.encode_image(big[:40])), "batch 40 vs 256"
+print("ok")
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, OVHIP_ROWPARTS="1", OV_ROOT=root), stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0 and "ok" in p.stdout, p.stderr[-3000:]
+
+
 def test_zero_shot_cli_from_checkpoint_directory(tmp_path):
     """SURVEY 8f row 1 + row a8, end to end and image-sensitive: weights -> checkpoint.save_pretrained (open_clip_config.json +
     open_clip_pytorch_model.bin, what ov-zero-shot-test.py:37-56 loads) -> `python -m openvision_amd.zero_shot` on the five testcat PNG

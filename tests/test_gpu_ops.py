@@ -730,6 +730,35 @@ def test_gemm_tn_matches_transposed_operands(Mc, NI, NJ, chunk):
     assert torch.equal(got, ref2)
 
 
+@pytest.mark.parametrize("M,N,K", [(65535, 1024, 1024), (65792, 1024, 256), (257, 1024, 4096), (1500, 768, 320), (12336, 1024, 256), (300, 192, 192)])
+def test_gemm_rowparts_are_the_row_partial_sums_of_the_output(M, N, K):
+    """ov_gemm_rowparts: the residual GEMM leaves {sum, sum of squares} of every 32-column group of its OUTPUT rows -- from the
+    persistent kernel's epilogue (first two shapes: whole tiles and a ragged last row tile), from the skinny kernel's (M = 257, 300,
+    1500) or from the stand-alone pass behind the non-persistent kernel (M = 12336: 196 tiles) -- bitwise what ov_rowparts computes
+    from the stored output (one association order everywhere: a row's statistics must not depend on the kernel that wrote it), the
+    output itself bitwise the plain residual GEMM's, and ov_rowstats_finalize on them within fp32 rounding of the two-pass
+    ov_rowstats (transformer.py:15-30: the LayerNorm the folded QKV / c_fc GEMMs apply)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    r = (torch.randn(M, N, generator=g) * 3 + 0.7).to(torch.bfloat16).to(DEV)       # a mean comparable to the spread
+    want = H.gemm(a, w, b, epi=3, resid=r)
+    out, parts = H.gemm_rowparts(a, w, b, r)
+    assert torch.equal(out, want)
+    ref = H.rowparts(out)
+    assert not torch.isnan(parts).any()
+    assert torch.equal(parts, ref)
+    x = out.float()
+    np.testing.assert_allclose(ref[..., 0].cpu().numpy(), x.view(M, N // 32, 32).sum(-1).cpu().numpy(), rtol=1e-5, atol=1e-4)
+    st, st2 = H.rowstats_finalize(parts), H.rowstats(out)
+    assert (st[:, 0] - st2[:, 0]).abs().max().item() < 1e-5 and ((st[:, 1] - st2[:, 1]).abs() / st2[:, 1]).max().item() < 2e-5
+    # in place (C aliases R, as the tower calls it): the same
+    x2 = r.clone()
+    _, parts2 = H.gemm_rowparts(a, w, b, x2, out=x2)
+    assert torch.equal(x2, want) and torch.equal(parts2, ref)
+
+
 @pytest.mark.parametrize("variant", ["1", "2", "3", "4"])
 def test_gemm_kernel_variants_agree_bitwise_with_the_default(variant):
     """OVHIP_GEMM_VARIANT (read once per process, so each variant runs in a child process): the simple two-stage kernel (1), the
