@@ -782,9 +782,17 @@ __device__ __forceinline__ void epilogue_stream(const GemmArgs& g, f32x4_t (&acc
         else wait_vmcnt<(YOUNGER)>();                                         \
         pin_rows(I0, I1);                                                     \
     } while (0)
+#ifndef OVHIP_EXP_HALF_EPI
+#define OVHIP_EXP_HALF_EPI 0     /* timing experiment (WRONG results): bias / GELU epilogues leave out passes 4-7 -- what hiding half of the epilogue could gain at most */
+#endif
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         if (wm == 1 && g.epi_prio > 0 && i == g.epi_prio) __builtin_amdgcn_s_setprio(0);
+        if (OVHIP_EXP_HALF_EPI == 1 && EPI < OV_EPI_BIAS_RESIDUAL && i >= 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(acc[i][j]));      // (keeps the accumulators, hence the MFMAs, alive)
+            continue;
+        }
         if (EPI >= OV_EPI_BIAS_RESIDUAL && i == 4) {
 #pragma unroll
             for (int k = 4; k < 8; ++k) load_resid(k);
@@ -809,7 +817,7 @@ __device__ __forceinline__ void epilogue_stream(const GemmArgs& g, f32x4_t (&acc
                 v23 += f32x2_t{bv[j][2], bv[j][3]};
             }
             if (KEEP) pk2[j] = u32x2_t{pack_bf16x2(v01[0], v01[1]), pack_bf16x2(v23[0], v23[1])};
-            if (EPI == OV_EPI_BIAS_GELU_ERF) gelu_erf_f2x2(v01, v23);
+            if (EPI == OV_EPI_BIAS_GELU_ERF && !(OVHIP_EXP_HALF_EPI == 2 && i >= 4)) gelu_erf_f2x2(v01, v23);      // (== 2: all stores, half the GELU)
             if (EPI == OV_EPI_BIAS_GELU_TANH) { v01 = gelu_tanh_f2(v01); v23 = gelu_tanh_f2(v23); }
             pk[j] = u32x2_t{pack_bf16x2(v01[0], v01[1]), pack_bf16x2(v23[0], v23[1])};
         }
@@ -934,6 +942,13 @@ __device__ __forceinline__ void epilogue_stream_lds(const GemmArgs& g, f32x4_t (
 #pragma unroll
     for (int i = 0; i <= 8; ++i) {
         if (wm == 1 && g.epi_prio > 0 && i == g.epi_prio) __builtin_amdgcn_s_setprio(0);
+        if (OVHIP_EXP_HALF_EPI == 1 && EPI < OV_EPI_BIAS_RESIDUAL && i > 4) {
+            if (i < 8) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(acc[i][j]));
+            }
+            continue;
+        }
         if (EPI >= OV_EPI_BIAS_RESIDUAL && i == 4) {
 #pragma unroll
             for (int k = 4; k < 8; ++k) load_resid(k);
@@ -1026,8 +1041,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist(const GemmArgs 
         }
     }
 
-    const int srow = tid >> 2;
-    const int schunk = (tid & 3) ^ swz4(srow);
     TileSrc cur, nxt;
     int64_t m0, nm0 = 0;
     int n0, nn0 = 0;
@@ -1172,6 +1185,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist(const GemmArgs 
                 if (KIND == 0) {
                     if (p == 3) {
                         if (strict) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        else if (OVHIP_EXP_HALF_EPI == 1 && EPI < OV_EPI_BIAS_RESIDUAL) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                         else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
                     }
                 } else if (KIND == 1) {
