@@ -683,7 +683,10 @@ __device__ __forceinline__ void epilogue_stream(const GemmArgs& g, f32x4_t (&acc
                                                 int64_t m0, int n0, int wave, int lane, bool edge, unsigned long long* wst,
                                                 char* stats_lds = nullptr) {
     const int wm = wave >> 2, wn = wave & 3;
-    const int fr = lane & 15, fq = lane >> 4;
+    // every per-lane constant of the epilogue is rebuilt per tile from an opaque lane id: as invariants of the tile loop hipcc carried
+    // them through the main loop (or spilled them)
+    const int lane_f = fresh_lane();
+    const int fr = lane_f & 15, fq = lane_f >> 4;
     const int cb = (fq & 1) * 16 + (fq >> 1) * 8;                 // column of this lane's 16-byte chunk inside a 32-column pair
     const int n_lo = n0 + wn * 64 + cb;                           // pair 0; pair 1 is + 32
     const bool ncol0 = n_lo + 8 <= g.N, ncol1 = n_lo + 40 <= g.N;
@@ -1119,6 +1122,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist(const GemmArgs 
     // every wave 32 rows of {mean, rstd} (dword granules, so a clamped row never shifts its neighbours)
     auto stage_params = [&](int slot, int64_t mm, int nn) {
         char* dst = smem + PRM_OFF + slot * 4096;
+        const int lane = fresh_lane();                  // (shadows the kernel's: rebuilt per tile, see fresh_lane)
         int c = nn + lane * 4;
         c = c + 4 <= g.N ? c : g.N - 4;
         if (wave == 0 && g.bias != nullptr) __builtin_amdgcn_global_load_lds((gptr_t)(g.bias + c), (lptr_t)dst, 16, 0, 0);
@@ -1153,8 +1157,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist(const GemmArgs 
     bool strict = true;      // K-tile 1 wait of this tile must not count on 16 younger stores (first tile / after an edge tile)
     bool has_next = false;
     int titer = 0;
+#ifndef OVHIP_STAMPS
+#define OVHIP_STAMPS 0       /* 1: the s_memtime diagnostics of tools/gemm_stamps.py / gemm_wave_stamps.py -- a VARIANT build (tools/build_variant.py */
+#endif                       /* stamps gemm.hip -DOVHIP_STAMPS=1, OVHIP_LIB=libovhip_stamps.so); compiled out of the product: their address arithmetic cost registers */
     auto stamp = [&](int k) {
-        if (g.stamps != nullptr && tid == 0 && titer < g.stamp_slots)
+        if (OVHIP_STAMPS && g.stamps != nullptr && tid == 0 && titer < g.stamp_slots)
             g.stamps[((size_t)bid * g.stamp_slots + titer) * 8 + k] = __builtin_amdgcn_s_memtime();
     };
     f32x4_t acc[8][4];
@@ -1221,7 +1228,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist(const GemmArgs 
         stamp(0);
         const int tnext = tcur + nper;
         has_next = tnext < xcnt;
-        if (has_next) set_tile(nxt, nm0, nn0);
         ktile(IntC<0>{});
         cb ^= STAGE_BYTES;
         stamp(4);
@@ -1233,14 +1239,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist(const GemmArgs 
             ktile(IntC<2>{});
             cb ^= STAGE_BYTES;
             advance(cur);
-            if (g.stamps != nullptr) {                             // diagnostics only: where inside the main loop the time goes
+            if (OVHIP_STAMPS && g.stamps != nullptr) {             // diagnostics only: where inside the main loop the time goes
                 if (t == 3) stamp(6);
                 else if (t == 7) stamp(7);
             }
         }
+        // the next tile's staging pointers only now, in front of the K-tile that first uses them: set up at the top of the tile they
+        // were 8 registers live (or spilled and reloaded) through the whole main loop
+        if (has_next) set_tile(nxt, nm0, nn0);
         ktile(IntC<3>{});
         stamp(1);
-        unsigned long long* wst = (g.wstamps != nullptr && titer < g.stamp_slots)
+        unsigned long long* wst = (OVHIP_STAMPS && g.wstamps != nullptr && titer < g.stamp_slots)
                                       ? g.wstamps + (((size_t)bid * g.stamp_slots + titer) * 8 + wave) * 8 : nullptr;
         if (wst != nullptr && lane == 0) wst[0] = __builtin_amdgcn_s_memtime();
         if (wm == 0) __builtin_amdgcn_s_barrier();                 // re-align: every wave is past its last COMPUTE segment

@@ -3,6 +3,12 @@ the numbers below are in units of 100 cycles, and ticks / wall time of the stamp
 import os, sys, torch, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+# the s_memtime stamps are compiled out of the product library: this tool needs the variant build
+#   python tools/build_variant.py stamps gemm.hip -DOVHIP_STAMPS=1        (on the build host; the .so travels with gpurun)
+if "OVHIP_LIB" not in os.environ:
+    if not os.path.exists(os.path.join(ROOT, "openvision_amd", "libovhip_stamps.so")):
+        sys.exit("build the stamps variant first: python tools/build_variant.py stamps gemm.hip -DOVHIP_STAMPS=1")
+    os.environ["OVHIP_LIB"] = "libovhip_stamps.so"
 import hipops as H
 from openvision_amd import _lib
 lib = _lib.load()

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Run ON the GPU box (via gpurun) from the repo root: the evidence files of a round, into gpurun_out/ (copied into profiles/ by hand /
 # tools/collect_profiles.py).  Usage: bash tools/round_evidence.sh rNN
+# Before sending: python tools/build_variant.py stamps gemm.hip -DOVHIP_STAMPS=1   (the stamp tools load libovhip_stamps.so)
 set -e
 TAG=${1:-rXX}
 OUT=$PWD/gpurun_out
