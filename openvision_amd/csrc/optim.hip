@@ -61,8 +61,9 @@ struct AdamArgs {
 __device__ __forceinline__ void adam_one(float& p, float g, unsigned short& mu, float& nu, const AdamArgs& a, float s) {
     // every product and sum rounded on its own (no FMA contraction): the arithmetic of the restated optax formulas, bit for bit
     g = __fmul_rn(g, s);
-    const float m = round_bf16(__fadd_rn(__fmul_rn(a.b1, bf16_bits_to_f32(mu)), __fmul_rn(1.0f - a.b1, g)));
-    const float v = __fadd_rn(__fmul_rn(a.b2, nu), __fmul_rn(__fmul_rn(1.0f - a.b2, g), g));
+    // optax.scale_by_adam: the update is formed from the fp32 moment; only the STORED copy is cast to mu_dtype afterwards
+    const float m = __fadd_rn(__fmul_rn(a.b1, bf16_bits_to_f32(mu)), __fmul_rn(1.0f - a.b1, g));
+    const float v = __fadd_rn(__fmul_rn(a.b2, nu), __fmul_rn(1.0f - a.b2, __fmul_rn(g, g)));
     mu = f32_to_bf16_bits(m);
     nu = v;
     const float u = __fdiv_rn(__fdiv_rn(m, a.bc1), __fadd_rn(__fsqrt_rn(__fdiv_rn(v, a.bc2)), a.eps));

@@ -56,26 +56,43 @@ def _pad_mlp(ts: List[torch.Tensor], mlp: int, mlp_pad: int) -> List[torch.Tenso
 
 
 class _Pool:
-    """Grow-only pool of device buffers (saved activations: 19 GB at L/14, B = 256; workspaces): a step takes what it needs in
-    forward and hands it back at the end of backward, so steady-state training allocates nothing per step."""
+    """Grow-only pool of device buffers, one free list per purpose ("saved": the activations a forward keeps for its backward, 19 GB at
+    L/14, B = 256; "ws": kernel workspaces): a step takes what it needs in forward and hands it back at the end of backward, so
+    steady-state training allocates nothing per step.  Retention sizes itself: per purpose the pool keeps as many free buffers as
+    were ever outstanding at once (one saved buffer per chunk of `set_backward_chunk_layers`, one workspace), and a request is served
+    by the SMALLEST free buffer of its own purpose that fits, so a workspace never takes a saved-activation buffer."""
 
     def __init__(self):
-        self.free: List[torch.Tensor] = []
+        self.lists = {}                    # purpose -> free buffers, ascending size
+        self.out = {}                      # purpose -> buffers currently handed out
+        self.peak = {}                     # purpose -> high-water mark of `out`
 
-    def take(self, nbytes: int, device) -> torch.Tensor:
-        for i, t in enumerate(self.free):
+    @property
+    def free(self) -> List[torch.Tensor]:
+        return [t for lst in self.lists.values() for t in lst]
+
+    def take(self, nbytes: int, device, kind: str = "ws") -> torch.Tensor:
+        lst = self.lists.setdefault(kind, [])
+        self.out[kind] = self.out.get(kind, 0) + 1
+        self.peak[kind] = max(self.peak.get(kind, 0), self.out[kind])
+        for i, t in enumerate(lst):
             if t.device == device and t.numel() >= nbytes:
-                t = self.free.pop(i)
+                t = lst.pop(i)
                 t._ovhip_gen += 1              # whoever still holds it from an earlier step can tell it was recycled
                 return t
         t = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=device)
-        t._ovhip_gen = 0
+        t._ovhip_gen, t._ovhip_kind = 0, kind
         return t
 
     def give(self, t: torch.Tensor) -> None:
-        self.free.append(t)
-        self.free.sort(key=lambda x: x.numel())
-        del self.free[:-4]                 # keep the four largest
+        kind = getattr(t, "_ovhip_kind", "ws")
+        lst = self.lists.setdefault(kind, [])
+        if any(u is t for u in lst):
+            return
+        self.out[kind] = max(0, self.out.get(kind, 0) - 1)
+        lst.append(t)
+        lst.sort(key=lambda x: x.numel())
+        del lst[:-max(1, self.peak.get(kind, 1))]        # too many: the smallest go (a grown request made them useless)
 
 
 def _train_state(transformer):
@@ -123,7 +140,7 @@ class _TowerFn(torch.autograd.Function):
                 bw = _lib.BlockWeights(*[C.c_void_p(t.data_ptr()) for t in ts], None, None)
                 check(lib.ov_tower_set_block(handle, i, C.byref(bw)), "ov_tower_set_block")
             xb = x.detach().to(torch.bfloat16).contiguous().clone()
-            saved = pool.take(lib.ov_tower_saved_bytes(handle, bsz, seq), x.device)
+            saved = pool.take(lib.ov_tower_saved_bytes(handle, bsz, seq), x.device, "saved")
             nbytes = lib.ov_tower_workspace_bytes(handle, bsz, seq)
             ws = pool.take(nbytes, x.device)
             check(lib.ov_tower_forward_saving(handle, ptr(xb), ptr(saved), bsz, seq, ptr(ws), nbytes, stream_ptr()),
@@ -157,8 +174,7 @@ class _TowerFn(torch.autograd.Function):
             check(lib.ov_tower_backward(handle, ptr(ctx.saved), ptr(dx), garr, bsz, seq, ptr(ws), nbytes, stream_ptr()),
                   "ov_tower_backward")
             ctx.pool.give(ws)
-            if not any(t is ctx.saved for t in ctx.pool.free):
-                ctx.pool.give(ctx.saved)     # ordered on the stream: the next forward's writes come after this backward's reads
+            ctx.pool.give(ctx.saved)         # ordered on the stream: the next forward's writes come after this backward's reads
         finally:
             lib.ov_tower_destroy(handle)
         mlp = ctx.mlp                                             # drop the (exactly zero) gradients of the MLP padding
@@ -397,6 +413,26 @@ class FusedAdamW:
         from .model import invalidate_packed
         invalidate_packed()
 
+    def state_dict(self) -> dict:
+        """Step count and the flat moments per group, with the names, shapes and offsets that say what lies where (the reference
+        trainer checkpoints its optax state the same way: src/main_clip.py, the `opt` entry of the checkpoint tree)."""
+        return dict(t=self.t, hyper=dict(b1=self.b1, b2=self.b2, eps=self.eps),
+                    groups=[dict(names=[n for n, _ in g["params"]], shapes=[tuple(p.shape) for _, p in g["params"]], offs=list(g["offs"]),
+                                 wd=g["wd"], mu=g["mu"].detach().clone(), nu=g["nu"].detach().clone()) for g in self.groups])
+
+    def load_state_dict(self, sd: dict) -> None:
+        """Restore what `state_dict` returned; the parameter layout (names, shapes, offsets per group) must be the one of this model."""
+        if len(sd["groups"]) != len(self.groups):
+            raise ValueError(f"optimizer state has {len(sd['groups'])} groups, this optimizer {len(self.groups)}")
+        for g, s in zip(self.groups, sd["groups"]):
+            mine = ([n for n, _ in g["params"]], [tuple(p.shape) for _, p in g["params"]], list(g["offs"]))
+            if (list(s["names"]), [tuple(x) for x in s["shapes"]], list(s["offs"])) != mine:
+                raise ValueError("optimizer state was saved for a different parameter layout")
+        for g, s in zip(self.groups, sd["groups"]):
+            g["mu"].copy_(s["mu"].to(g["mu"].device, torch.bfloat16))
+            g["nu"].copy_(s["nu"].to(g["nu"].device, torch.float32))
+        self.t = int(sd["t"])
+
     def zero_grad(self) -> None:
         """Zero the flat gradient buffers; ``.grad`` stays a view of them (set_to_none would detach the views)."""
         for g in self.groups:
@@ -408,11 +444,15 @@ class FusedAdamW:
         self._rearm()
 
     def _collect(self) -> None:
-        """A ``.grad`` that autograd replaced instead of accumulating in place is copied back into its flat slot."""
+        """A ``.grad`` that autograd replaced instead of accumulating in place is copied back into its flat slot; the slot of a
+        parameter whose ``.grad`` is None (set_to_none by someone else's zero_grad) is zeroed, so no stale gradient is applied."""
         for g in self.groups:
             for (_, p), o in zip(g["params"], g["offs"]):
                 want = g["grad"][o:o + p.numel()]
-                if p.grad is not None and p.grad.data_ptr() != want.data_ptr():
+                if p.grad is None:                                   # model.zero_grad(set_to_none=True): no gradient this step,
+                    want.zero_()                                     # not last step's values
+                    p.grad = want.view(p.shape)
+                elif p.grad.data_ptr() != want.data_ptr():
                     want.copy_(p.grad.detach().reshape(-1).float())
                     p.grad = want.view(p.shape)
 
@@ -432,6 +472,9 @@ class FusedAdamW:
         runs under the backward of the earlier ones.  ``all_reduce_gradients`` then only launches what is left and waits.  Call
         ``zero_grad()`` (this class's) before every backward: it re-arms the buckets.  ``always_collective`` issues the collectives
         in a world of one rank as well (exercises the RCCL calls on a single GPU)."""
+        for h in getattr(self, "_ov_hooks", []):                # a second call (new bucket size, new group) replaces the hooks:
+            h.remove()                                          # two hooks per parameter would arm the buckets at half the gradients
+        self._ov_hooks = []
         self._ov = dict(world=int(world_size), group=group, works=[], pending=[], launched=[], force=bool(always_collective))
         self._ov_buckets = []                                   # (group index, start, stop)
         per = max(1, self.bucket_bytes // 4)
@@ -444,7 +487,7 @@ class FusedAdamW:
                 mine = [bi for bi, (bg, s, e) in enumerate(self._ov_buckets) if bg == gi and s < o + p.numel() and o < e]
                 for bi in mine:
                     self._ov_members[bi].append((gi, pi))
-                p.register_post_accumulate_grad_hook(self._make_hook(gi, pi, o, mine))
+                self._ov_hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(gi, pi, o, mine)))
         self._rearm()
 
     def _rearm(self) -> None:

@@ -25,8 +25,8 @@ def adamw_step(p, g, mu, nu, step, lr, b1=0.9, b2=0.95, eps=1e-8, wd=0.0, grad_s
         n = np.float32(gnorm if gnorm is not None else np.sqrt(((g.astype(np.float64) * grad_scale) ** 2).sum()))
         s = s * (np.float32(clip_norm) / max(n, np.float32(clip_norm)))      # scale and clip factor folded into one multiplier
     g = g.astype(np.float32) * s
-    mu = _bf16(np.float32(b1) * mu + np.float32(1.0 - b1) * g)
-    nu = (np.float32(b2) * nu + (np.float32(1.0 - b2) * g) * g).astype(np.float32)
+    mu = (np.float32(b1) * mu + np.float32(1.0 - b1) * g).astype(np.float32)          # fp32 here; cast for storage below
+    nu = (np.float32(b2) * nu + np.float32(1.0 - b2) * (g * g)).astype(np.float32)
     u = (mu / np.float32(1.0 - b1 ** step)) / (np.sqrt(nu / np.float32(1.0 - b2 ** step)) + np.float32(eps))
     p = (p - np.float32(lr) * (u + np.float32(wd) * p)).astype(np.float32)
-    return p, mu, nu
+    return p, _bf16(mu), nu

@@ -154,3 +154,81 @@ def test_optimizer_oracle_self_consistency_and_decay_filter():
     assert "visual.conv1.weight" in dec and "text_projection" in dec and "transformer.resblocks.0.mlp.c_fc.weight" in dec
     assert not ({"logit_scale", "token_embedding.weight", "positional_embedding", "visual.positional_embedding",
                  "visual.class_embedding", "ln_final.weight", "transformer.resblocks.0.mlp.c_fc.bias"} & dec)
+
+
+def test_optimizer_update_is_formed_from_the_unrounded_first_moment():
+    """optax.scale_by_adam forms the update from the fp32 moment and casts mu to mu_dtype only for storage: a gradient whose first
+    moment is NOT representable in bf16 must move the parameter by the unrounded amount (oracle/optim_ref.py; the HIP kernel is
+    held to this oracle in tests/test_gpu_model.py)."""
+    from oracle import optim_ref as O
+    g = np.array([1.2345678], np.float32)                                   # (1 - b1) * g has more than 8 significant bits
+    z = np.zeros(1, np.float32)
+    p1, mu, nu = O.adamw_step(z, g, z, z, 1, 1.0, b1=0.9, b2=0.95, eps=0.0)
+    m32 = np.float32(1.0 - 0.9) * g
+    assert O._bf16(m32)[0] != m32[0] and mu[0] == O._bf16(m32)[0]           # stored rounded ...
+    want = -(m32 / np.float32(1.0 - 0.9)) / np.sqrt((np.float32(1.0 - 0.95) * (g * g)) / np.float32(1.0 - 0.95))
+    assert p1[0] == np.float32(want[0])                                      # ... used unrounded
+    assert nu[0] == (np.float32(1.0 - 0.95) * (g * g))[0]                    # (1 - b2) * (g * g), optax's grouping
+
+
+def test_training_pool_keeps_what_a_step_needs_and_serves_by_purpose():
+    """training._Pool: one free list per purpose, smallest fit, and as many retained buffers as were ever outstanding together (one
+    saved-activation buffer per backward chunk), so chunked training re-uses all its buffers every step."""
+    from openvision_amd.training import _Pool
+    pool, dev = _Pool(), torch.device("cpu")
+    saved = [pool.take(1000 * (i + 1), dev, "saved") for i in range(6)]      # six chunks alive at once
+    ws = pool.take(100, dev)
+    pool.give(ws)
+    for t in saved:
+        pool.give(t)
+    assert len(pool.lists["saved"]) == 6 and len(pool.lists["ws"]) == 1
+    ptrs = {t.data_ptr() for t in saved}
+    again = [pool.take(1000 * (i + 1), dev, "saved") for i in range(6)]
+    assert {t.data_ptr() for t in again} == ptrs                            # nothing reallocated
+    assert [t.numel() for t in again] == [t.numel() for t in saved]         # smallest fit: each request got its own size back
+    assert all(t._ovhip_gen == 1 for t in again)
+    w2 = pool.take(50, dev)
+    assert w2.data_ptr() == ws.data_ptr()                                   # a workspace request never takes a saved buffer
+    pool.give(w2)
+    pool.give(w2)                                                           # handing back twice is harmless
+    assert len(pool.lists["ws"]) == 1
+
+
+def test_fused_adamw_state_dict_hooks_and_none_gradients():
+    """training.FusedAdamW host logic on CPU tensors: state_dict/load_state_dict round-trips step count and moments and refuses another
+    layout; a second overlap_gradient_exchange replaces the hooks instead of doubling them; a parameter whose .grad was set to None
+    contributes zeros, not last step's gradient."""
+    from openvision_amd import training
+    cfg = preset("vit-tiny-patch16-160")
+    m = create_model(cfg, state_dict=synth.make_state_dict(cfg))
+    opt = training.FusedAdamW(m, lr=1e-3, bucket_bytes=1 << 20)
+    opt.t = 7
+    for g in opt.groups:
+        g["mu"].copy_(torch.randn(g["mu"].numel()).bfloat16())
+        g["nu"].copy_(torch.rand(g["nu"].numel()))
+    sd = opt.state_dict()
+    m2 = create_model(cfg, state_dict=synth.make_state_dict(cfg))
+    opt2 = training.FusedAdamW(m2, lr=1e-3)
+    opt2.load_state_dict(sd)
+    assert opt2.t == 7 and all(torch.equal(a["mu"], b["mu"]) and torch.equal(a["nu"], b["nu"]) for a, b in zip(opt.groups, opt2.groups))
+    sd["groups"][0]["mu"].zero_()
+    assert opt.groups[0]["mu"].abs().sum() > 0                               # the state dict holds copies
+    bad = dict(sd, groups=[dict(sd["groups"][0], offs=[o + 4 for o in sd["groups"][0]["offs"]]), sd["groups"][1]])
+    with pytest.raises(ValueError):
+        opt2.load_state_dict(bad)
+    # hooks: the second registration replaces the first
+    opt.overlap_gradient_exchange(1)
+    opt.overlap_gradient_exchange(1)
+    n_params = sum(len(g["params"]) for g in opt.groups)
+    assert len(opt._ov_hooks) == n_params
+    opt.zero_grad()
+    loss = sum((p * 2.0).sum() for p in m.parameters())
+    loss.backward()
+    assert all(x == 0 for x in opt._ov["pending"]) and all(opt._ov["launched"])   # each bucket armed exactly once per gradient
+    assert opt.all_reduce_gradients(1) == 1.0
+    assert all(bool((g["grad"][:16] == 2.0).all()) for g in opt.groups)
+    # a .grad dropped behind the optimiser's back is a zero gradient
+    name, p = opt.groups[0]["params"][0]
+    p.grad = None
+    opt._collect()
+    assert p.grad is not None and float(p.grad.abs().sum()) == 0.0 and p.grad.data_ptr() == opt.groups[0]["grad"].data_ptr()
