@@ -43,7 +43,6 @@ struct GemmArgs {
     int epi_prio;                        // persistent kernel: n > 0: waves 4-7 (the arbitration losers) run epilogue passes < n at s_setprio 1
     ov_bf16* C2; int64_t ldc2;           // ov_gemm_keep: second output = the GELU epilogue's pre-activation (acc + bias), bf16
     float* psum;                         // gemm_bf16_pp_tn: [gridDim.y][M] column sums of P over the split's rows (NULL = off)
-    int exp;                             // persistent kernel: experiment bits (OVHIP_GEMM_EXP; none defined at present)
     float* rowpart;                      // residual epilogue (persistent direct form, skinny kernel): {sum, sum of squares} of every
                                          // 32-column group of every OUTPUT row, [M][N / 32][2] fp32 (common.h: row statistics); NULL = off
 };
@@ -785,17 +784,9 @@ __device__ __forceinline__ void epilogue_stream(const GemmArgs& g, f32x4_t (&acc
         else wait_vmcnt<(YOUNGER)>();                                         \
         pin_rows(I0, I1);                                                     \
     } while (0)
-#ifndef OVHIP_EXP_HALF_EPI
-#define OVHIP_EXP_HALF_EPI 0     /* timing experiment (WRONG results): bias / GELU epilogues leave out passes 4-7 -- what hiding half of the epilogue could gain at most */
-#endif
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         if (wm == 1 && g.epi_prio > 0 && i == g.epi_prio) __builtin_amdgcn_s_setprio(0);
-        if (OVHIP_EXP_HALF_EPI == 1 && EPI < OV_EPI_BIAS_RESIDUAL && i >= 4) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(acc[i][j]));      // (keeps the accumulators, hence the MFMAs, alive)
-            continue;
-        }
         if (EPI >= OV_EPI_BIAS_RESIDUAL && i == 4) {
 #pragma unroll
             for (int k = 4; k < 8; ++k) load_resid(k);
@@ -820,7 +811,7 @@ __device__ __forceinline__ void epilogue_stream(const GemmArgs& g, f32x4_t (&acc
                 v23 += f32x2_t{bv[j][2], bv[j][3]};
             }
             if (KEEP) pk2[j] = u32x2_t{pack_bf16x2(v01[0], v01[1]), pack_bf16x2(v23[0], v23[1])};
-            if (EPI == OV_EPI_BIAS_GELU_ERF && !(OVHIP_EXP_HALF_EPI == 2 && i >= 4)) gelu_erf_f2x2(v01, v23);      // (== 2: all stores, half the GELU)
+            if (EPI == OV_EPI_BIAS_GELU_ERF) gelu_erf_f2x2(v01, v23);
             if (EPI == OV_EPI_BIAS_GELU_TANH) { v01 = gelu_tanh_f2(v01); v23 = gelu_tanh_f2(v23); }
             pk[j] = u32x2_t{pack_bf16x2(v01[0], v01[1]), pack_bf16x2(v23[0], v23[1])};
         }
@@ -945,13 +936,6 @@ __device__ __forceinline__ void epilogue_stream_lds(const GemmArgs& g, f32x4_t (
 #pragma unroll
     for (int i = 0; i <= 8; ++i) {
         if (wm == 1 && g.epi_prio > 0 && i == g.epi_prio) __builtin_amdgcn_s_setprio(0);
-        if (OVHIP_EXP_HALF_EPI == 1 && EPI < OV_EPI_BIAS_RESIDUAL && i > 4) {
-            if (i < 8) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(acc[i][j]));
-            }
-            continue;
-        }
         if (EPI >= OV_EPI_BIAS_RESIDUAL && i == 4) {
 #pragma unroll
             for (int k = 4; k < 8; ++k) load_resid(k);
@@ -1192,7 +1176,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist(const GemmArgs 
                 if (KIND == 0) {
                     if (p == 3) {
                         if (strict) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        else if (OVHIP_EXP_HALF_EPI == 1 && EPI < OV_EPI_BIAS_RESIDUAL) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                         else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
                     }
                 } else if (KIND == 1) {
@@ -1514,12 +1497,6 @@ int gemm_stagger_classes() {
     return v;
 }
 
-int gemm_exp() {           // experiment bits of the persistent kernel (timing studies; 0 in production)
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("OVHIP_GEMM_EXP"); v = e ? atoi(e) : 0; }
-    return v;
-}
-
 int gemm_epi_prio() {
     static int v = -1;
     // default 4: waves 4-7 (younger, they lose every VALU / LDS arbitration against waves 0-3 and finish the epilogue 1.4 k cycles
@@ -1640,7 +1617,7 @@ extern "C" int ov_gemm(const ov_bf16* A, int64_t lda, const ov_bf16* W, int64_t 
     if (tiles_m * tiles_n > 0x7fffffffLL || M > 0x7fff0000LL) return OV_ERR_UNSUPPORTED;    // 32-bit row indices in the kernels
     GemmArgs a{A, W, bias, C, R, lda, ldw, ldc, ldr, M, N, K, (int)tiles_m, (int)tiles_n,
                out_group, resid_mod, resid_off, g_colsum, g_rowstats, g_stamps, g_stamp_slots, g_wstamps, gemm_ngroup((int)tiles_m, (int)tiles_n, K), 0, 0, 0,
-               gemm_stagger(K), gemm_stagger_classes(), gemm_epi_prio(), g_keep, g_ldkeep, nullptr, gemm_exp(), g_rowpart};
+               gemm_stagger(K), gemm_stagger_classes(), gemm_epi_prio(), g_keep, g_ldkeep, nullptr, g_rowpart};
     hipStream_t st = (hipStream_t)stream;
     switch (epilogue) {
         case OV_EPI_BIAS: return launch<OV_EPI_BIAS>(a, st);
