@@ -43,6 +43,9 @@ struct GemmArgs {
     int epi_prio;                        // persistent kernel: n > 0: waves 4-7 (the arbitration losers) run epilogue passes < n at s_setprio 1
     ov_bf16* C2; int64_t ldc2;           // ov_gemm_keep: second output = the GELU epilogue's pre-activation (acc + bias), bf16
     float* psum;                         // gemm_bf16_pp_tn: [gridDim.y][M] column sums of P over the split's rows (NULL = off)
+    int rotmask;                         // persistent kernel, plain walk, half last n-tile (see HALF TILES): tiles_n - 1 when the workgroup
+                                         // stride is a multiple of tiles_n -- the n index is then rotated by the workgroup's tile count, so
+                                         // that every workgroup alternates between full and half tiles (0 = off)
     float* rowpart;                      // residual epilogue (persistent direct form, skinny kernel): {sum, sum of squares} of every
                                          // 32-column group of every OUTPUT row, [M][N / 32][2] fp32 (common.h: row statistics); NULL = off
 };
@@ -680,14 +683,18 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {          // lite
 template <int EPI, bool FOLD, bool MAPPED, bool KEEP = false, bool STATS = false>
 __device__ __forceinline__ void epilogue_stream(const GemmArgs& g, f32x4_t (&acc)[8][4], const char* prm,
                                                 int64_t m0, int n0, int wave, int lane, bool edge, unsigned long long* wst,
-                                                char* stats_lds = nullptr) {
-    const int wm = wave >> 2, wn = wave & 3;
+                                                bool htile, char* stats_lds = nullptr) {
+    // `htile` (a HALF TILE: at most 128 valid columns, see gemm_bf16_persist): the waves form a 4 x 2 grid of 64 x 64 sub-tiles, only
+    // acc[0..3] hold results and only passes 0-3 store.  Such a tile is an `edge` tile: every wait below is then a full drain.
+    const int wm = wave >> 2;
+    const int rb = htile ? (wave >> 1) * 64 : wm * 128;            // the wave's first row / column inside the tile
+    const int cw = htile ? (wave & 1) * 64 : (wave & 3) * 64;
     // every per-lane constant of the epilogue is rebuilt per tile from an opaque lane id: as invariants of the tile loop hipcc carried
     // them through the main loop (or spilled them)
     const int lane_f = fresh_lane();
     const int fr = lane_f & 15, fq = lane_f >> 4;
     const int cb = (fq & 1) * 16 + (fq >> 1) * 8;                 // column of this lane's 16-byte chunk inside a 32-column pair
-    const int n_lo = n0 + wn * 64 + cb;                           // pair 0; pair 1 is + 32
+    const int n_lo = n0 + cw + cb;                           // pair 0; pair 1 is + 32
     const bool ncol0 = n_lo + 8 <= g.N, ncol1 = n_lo + 40 <= g.N;
     // Residual rows (unpredicated, clamped addresses -- a predicated load makes hipcc serialise the loads behind
     // vmcnt(0)).  Every load of the epilogue is issued before its first store: rows of passes 0-3 now, rows of passes
@@ -695,7 +702,7 @@ __device__ __forceinline__ void epilogue_stream(const GemmArgs& g, f32x4_t (&acc
     u32x4_t rv[8][2];
     const int nc0 = ncol0 ? n_lo : g.N - 8, nc1 = ncol1 ? n_lo + 32 : g.N - 8;
     // !MAPPED: this lane's row of pass 0 (clamped for the residual read: rows past M re-read row M - 1, never stored)
-    const int64_t mbase = m0 + wm * 128 + fr;
+    const int64_t mbase = m0 + rb + fr;
     ov_bf16* const cbase = !MAPPED ? g.C + mbase * g.ldc + n_lo : nullptr;
     ov_bf16* const cbase2 = KEEP ? g.C2 + mbase * g.ldc2 + n_lo : nullptr;
     auto load_resid = [&](int i) {      // inline asm: the waits below are counted by hand (hipcc would use vmcnt(0))
@@ -707,7 +714,7 @@ __device__ __forceinline__ void epilogue_stream(const GemmArgs& g, f32x4_t (&acc
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rv[i][1]) : "v"(src + nc1));
             return;
         }
-        unsigned m = (unsigned)m0 + wm * 128 + i * 16 + fr;
+        unsigned m = (unsigned)m0 + rb + i * 16 + fr;
         m = m < (unsigned)g.M ? m : (unsigned)g.M - 1;
         const unsigned rrow = g.resid_mod ? (m % (unsigned)g.resid_mod) + g.resid_off : m;
         const ov_bf16* src = g.R + (int64_t)rrow * g.ldr;
@@ -722,16 +729,17 @@ __device__ __forceinline__ void epilogue_stream(const GemmArgs& g, f32x4_t (&acc
     // (s_waitcnt vmcnt(0)), i.e. behind the next tile's K-tile 1 that was issued a moment ago.
     f32x4_t bq[4], sq[4];
     f32x2_t stq[8];
-    const unsigned pa = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(prm + (wn * 64 + fq * 4) * 4);
-    const unsigned ra = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(prm + 2048 + (wm * 128 + fr) * 8);
+    const unsigned pa = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(prm + (cw + fq * 4) * 4);
+    const unsigned ra = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(prm + 2048 + (rb + fr) * 8);
     // (no branch between a read and its wait: a merge point would make hipcc copy the destination registers early)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bq[j]) : "v"(pa), "n"(j * 64));
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(sq[j]) : "v"(pa), "n"(1024 + j * 64));
     }
+    const unsigned ra2 = htile ? ra - 512u : ra;                   // half tile: passes 4-7 re-read the rows of passes 0-3 (in range, unused)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(stq[i]) : "v"(ra), "n"(i * 128));
+    for (int i = 0; i < 8; ++i) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(stq[i]) : "v"(i < 4 ? ra : ra2), "n"(i * 128));
     asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]), "+v"(sq[0]), "+v"(sq[1]), "+v"(sq[2]), "+v"(sq[3]));
     asm volatile("" : "+v"(stq[0]), "+v"(stq[1]), "+v"(stq[2]), "+v"(stq[3]), "+v"(stq[4]), "+v"(stq[5]), "+v"(stq[6]), "+v"(stq[7]));
@@ -747,7 +755,8 @@ __device__ __forceinline__ void epilogue_stream(const GemmArgs& g, f32x4_t (&acc
         }
     u32x4_t vo[8][2];
     auto put = [&](int i) {
-        const unsigned m = (unsigned)m0 + wm * 128 + i * 16 + fr;
+        const unsigned m = (unsigned)m0 + rb + i * 16 + fr;
+        const bool live = i < 4 || !htile;
         ov_bf16* dst;
         if (!MAPPED) {
             dst = cbase + (int64_t)(i * 16) * g.ldc;
@@ -759,7 +768,7 @@ __device__ __forceinline__ void epilogue_stream(const GemmArgs& g, f32x4_t (&acc
         for (int h = 0; h < 2; ++h) {
             u32x4_t o = vo[i][h];
             if (EPI >= OV_EPI_BIAS_RESIDUAL) o = epi_combine<EPI>(o, rv[i][h]);
-            if (m < (unsigned)g.M && (h ? ncol1 : ncol0)) store16<OVHIP_ST_DIRECT>(dst + h * 32, o);
+            if (m < (unsigned)g.M && (h ? ncol1 : ncol0) && live) store16<OVHIP_ST_DIRECT>(dst + h * 32, o);
             if (STATS) {
                 // this lane's 8 consecutive columns -> octet; fq 0 | 2 | 1 | 3 hold octets 0 | 1 | 2 | 3 of the 32-column group
                 float s8, q8;
@@ -768,7 +777,7 @@ __device__ __forceinline__ void epilogue_stream(const GemmArgs& g, f32x4_t (&acc
                 q8 = add_rowpair_even_first(add_halves_lo_first(q8));
                 // into the tile's [256 rows][8 groups] fp32-pair image in LDS; the workgroup writes it out in 64-byte row pieces
                 // behind the tile barrier (16 scattered 8-byte stores per pass measured slower than the pass over x they replace)
-                if (fq == 0) *(float2*)(stats_lds + ((wm * 128 + i * 16 + fr) * 8 + wn * 2 + h) * 8) = make_float2(s8, q8);
+                if (fq == 0 && live) *(float2*)(stats_lds + ((rb + i * 16 + fr) * 8 + (cw >> 5) + h) * 8) = make_float2(s8, q8);
             }
         }
     };
@@ -816,13 +825,13 @@ __device__ __forceinline__ void epilogue_stream(const GemmArgs& g, f32x4_t (&acc
             pk[j] = u32x2_t{pack_bf16x2(v01[0], v01[1]), pack_bf16x2(v23[0], v23[1])};
         }
         if (KEEP) {          // the pre-activation rows, same lane -> chunk map as the output (never MAPPED, never residual)
-            const unsigned m = (unsigned)m0 + wm * 128 + i * 16 + fr;
+            const unsigned m = (unsigned)m0 + rb + i * 16 + fr;
             ov_bf16* dst2 = cbase2 + (int64_t)(i * 16) * g.ldc2;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const u32x2_t s0 = __builtin_amdgcn_permlane16_swap(pk2[2 * h][0], pk2[2 * h + 1][0], false, false);
                 const u32x2_t s1 = __builtin_amdgcn_permlane16_swap(pk2[2 * h][1], pk2[2 * h + 1][1], false, false);
-                if (m < (unsigned)g.M && (h ? ncol1 : ncol0)) store16<OVHIP_ST_DIRECT>(dst2 + h * 32, u32x4_t{s0[0], s1[0], s0[1], s1[1]});
+                if (m < (unsigned)g.M && (h ? ncol1 : ncol0) && (i < 4 || !htile)) store16<OVHIP_ST_DIRECT>(dst2 + h * 32, u32x4_t{s0[0], s1[0], s0[1], s1[1]});
             }
         }
 #pragma unroll
@@ -851,11 +860,13 @@ __device__ __forceinline__ void epilogue_stream(const GemmArgs& g, f32x4_t (&acc
 // coalesced stores (16 TA cycles per instruction against ~70 for the row-per-lane form above), at the price of the LDS round trip.
 template <int EPI, bool FOLD, bool MAPPED>
 __device__ __forceinline__ void epilogue_stream_lds(const GemmArgs& g, f32x4_t (&acc)[8][4], char* img, const char* prm,
-                                                int64_t m0, int n0, int wave, int lane, bool edge, unsigned long long* wst) {
-    const int wm = wave >> 2, wn = wave & 3;
+                                                int64_t m0, int n0, int wave, int lane, bool edge, unsigned long long* wst, bool htile) {
+    const int wm = wave >> 2;
+    const int rb = htile ? (wave >> 1) * 64 : wm * 128;            // (see epilogue_stream)
+    const int cw = htile ? (wave & 1) * 64 : (wave & 3) * 64;
     const int fr = lane & 15, fq = lane >> 4;
     const int er = lane >> 3, ec = lane & 7;
-    const int n = n0 + wn * 64 + ec * 8;
+    const int n = n0 + cw + ec * 8;
     const bool ncol = n < g.N;
     // Residual rows (unpredicated, clamped addresses -- a predicated load makes hipcc serialise the loads behind
     // vmcnt(0)).  Every load of the epilogue is issued before its first store: rows of passes 0-3 now, rows of passes
@@ -865,7 +876,7 @@ __device__ __forceinline__ void epilogue_stream_lds(const GemmArgs& g, f32x4_t (
     auto load_resid = [&](int i) {      // inline asm: the waits below are counted by hand (hipcc would use vmcnt(0))
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
-            unsigned m = (unsigned)m0 + wm * 128 + i * 16 + it * 8 + er;
+            unsigned m = (unsigned)m0 + rb + i * 16 + it * 8 + er;
             m = m < (unsigned)g.M ? m : (unsigned)g.M - 1;
             const unsigned rrow = g.resid_mod ? (m % (unsigned)g.resid_mod) + g.resid_off : m;
             const ov_bf16* src = g.R + (int64_t)rrow * g.ldr + nc;
@@ -880,16 +891,17 @@ __device__ __forceinline__ void epilogue_stream_lds(const GemmArgs& g, f32x4_t (
     // (s_waitcnt vmcnt(0)), i.e. behind the next tile's K-tile 1 that was issued a moment ago.
     f32x4_t bq[4], sq[4];
     f32x2_t stq[8];
-    const unsigned pa = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(prm + (wn * 64 + fq * 4) * 4);
-    const unsigned ra = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(prm + 2048 + (wm * 128 + fr) * 8);
+    const unsigned pa = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(prm + (cw + fq * 4) * 4);
+    const unsigned ra = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(prm + 2048 + (rb + fr) * 8);
     // (no branch between a read and its wait: a merge point would make hipcc copy the destination registers early)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bq[j]) : "v"(pa), "n"(j * 64));
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(sq[j]) : "v"(pa), "n"(1024 + j * 64));
     }
+    const unsigned ra2 = htile ? ra - 512u : ra;                   // half tile: passes 4-7 re-read the rows of passes 0-3 (in range, unused)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(stq[i]) : "v"(ra), "n"(i * 128));
+    for (int i = 0; i < 8; ++i) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(stq[i]) : "v"(i < 4 ? ra : ra2), "n"(i * 128));
     asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]), "+v"(sq[0]), "+v"(sq[1]), "+v"(sq[2]), "+v"(sq[3]));
     asm volatile("" : "+v"(stq[0]), "+v"(stq[1]), "+v"(stq[2]), "+v"(stq[3]), "+v"(stq[4]), "+v"(stq[5]), "+v"(stq[6]), "+v"(stq[7]));
@@ -906,19 +918,20 @@ __device__ __forceinline__ void epilogue_stream_lds(const GemmArgs& g, f32x4_t (
     char* const wr = img + fr * 128 + (fq & 1) * 8;
     const int wsw = fr & 7;
     const char* const rd = img + er * 128 + ((ec ^ er) << 4);       // rows er and er + 8 share (row & 7)
-    ov_bf16* const cbase_lds = !MAPPED ? g.C + (m0 + wm * 128 + er) * g.ldc + n : nullptr;
+    ov_bf16* const cbase_lds = !MAPPED ? g.C + (m0 + rb + er) * g.ldc + n : nullptr;
     u32x4_t vo[8][2];
     auto put = [&](int i) {
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             u32x4_t o = vo[i][it];
             if (EPI >= OV_EPI_BIAS_RESIDUAL) o = epi_combine<EPI>(o, rv[i][it]);
-            const unsigned m = (unsigned)m0 + wm * 128 + i * 16 + it * 8 + er;
+            const unsigned m = (unsigned)m0 + rb + i * 16 + it * 8 + er;
+            const bool live = i < 4 || !htile;
             if (!MAPPED) {   // no row map: the lane's row pointer of pass 0, stepped by whole rows
-                if (m < (unsigned)g.M && ncol) store16<OVHIP_ST_LDS>(cbase_lds + (int64_t)(i * 16 + it * 8) * g.ldc, o);
+                if (m < (unsigned)g.M && ncol && live) store16<OVHIP_ST_LDS>(cbase_lds + (int64_t)(i * 16 + it * 8) * g.ldc, o);
                 continue;
             }
-            if (m < (unsigned)g.M && ncol) {
+            if (m < (unsigned)g.M && ncol && live) {
                 const unsigned orow = g.out_group ? m + m / (unsigned)g.out_group + 1 : m;
                 store16<OVHIP_ST_LDS>(g.C + (int64_t)orow * g.ldc + n, o);
             }
@@ -1009,6 +1022,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist(const GemmArgs 
         pc = pq + (xcd < pr ? 1 : 0);
         xstart = 0;
         xcnt = pc * g.tiles_n;
+    } else if (g.rotmask) {              // rotated plain walk: runs of whole row panels (the rotation permutes the tiles of a panel)
+        const int pq = g.tiles_m >> 3, pr = g.tiles_m & 7;
+        xstart = (xcd * pq + (xcd < pr ? xcd : pr)) * g.tiles_n;
+        xcnt = (pq + (xcd < pr ? 1 : 0)) * g.tiles_n;
     } else {
         const int q8 = nwg >> 3, r8 = nwg & 7;
         xstart = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
@@ -1037,6 +1054,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist(const GemmArgs 
     const int rad0 = grouped ? g.ngroup : g.tiles_n;
     const int rad1 = grouped ? pc : 0x7fffffff;
     int d0, d1, d2, s0, s1, s2;                       // digits of the NEXT tile to set up / of the stride
+    int rotk = 0;                                     // tiles set up so far (rotated walk)
     {
         const int base = grouped ? li : xstart + li;
         d0 = base % rad0;
@@ -1054,7 +1072,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist(const GemmArgs 
         const int tid_f = wave * 64 + fresh_lane();
         const int srow = tid_f >> 2;
         const int schunk = (tid_f & 3) ^ swz4(srow);
-        const int tm = p0 + d1, tn = d2 * rad0 + d0;
+        // (rotated walk: this workgroup's k-th tile takes n index (d0 + k) mod tiles_n; its d0 never changes, the stride being a
+        // multiple of tiles_n, and the tiles_n workgroups that share a row panel in a round hold distinct d0)
+        const int tm = p0 + d1, tn = g.rotmask ? ((d0 + rotk) & g.rotmask) : d2 * rad0 + d0;
+        ++rotk;
         d0 += s0;
         if (d0 >= rad0) { d0 -= rad0; ++d1; }
         d1 += s1;
@@ -1119,13 +1140,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist(const GemmArgs 
         }
     };
 
-    const int wm = wave >> 2, wn = wave & 3;
-    const int fr = lane & 15, fq = lane >> 4;
-    const int lsw = (fq ^ swz4(fr)) << 4;
-    const int a_lane = (wm * 128 + fr) * 64 + lsw;
-    const int w_lane = PIECE_BYTES + (wn * 64 + fr) * 64 + lsw;
+    const int wm = wave >> 2;
+    // HALF TILES.  A tile with at most 128 valid columns (the last n-tile of N = 384, 1152, ...: S/8's D = 384 leaves a quarter of the
+    // out-proj / c_proj MFMAs on padding otherwise) is computed by the waves as a 4 x 2 grid of 64 x 64 sub-tiles instead of 2 x 4 of
+    // 128 x 64: only the m-half-0 phases of a K-tile hold MFMAs (acc[0..3]), staging, waits and barriers are unchanged (same DMA
+    // count, so every counted wait stands), and each output element sums its products in the same order as in a full tile.
+    bool htile;
+    int a_lane, w_lane;
+    auto set_lanes = [&](int nn) {
+        htile = g.N - nn <= 128;
+        const int lf = fresh_lane();
+        const int fr = lf & 15, fq = lf >> 4;
+        const int lsw = (fq ^ swz4(fr)) << 4;
+        a_lane = ((htile ? (wave >> 1) * 64 : wm * 128) + fr) * 64 + lsw;
+        w_lane = PIECE_BYTES + ((htile ? (wave & 1) : (wave & 3)) * 64 + fr) * 64 + lsw;
+    };
     const int nt = g.K / BK;                                       // >= 3 (launcher)
     set_tile(cur, m0, n0);
+    set_lanes(n0);
 #pragma unroll
     for (int j = 0; j < 4; ++j) stage_piece(cur, 0, j);
     advance(cur);
@@ -1168,8 +1200,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist(const GemmArgs 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) wf[j] = *(const bf16x8_t*)(sp + w_lane + j * 1024);
             }
+            if (mh == 0 || !htile) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8_t*)(sp + a_lane + (mh * 4 + i) * 1024);
+                for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8_t*)(sp + a_lane + (mh * 4 + i) * 1024);
+            }
             if (KIND == 1 || KIND == 2) stage_piece(cur, nb, p);
             if (KIND == 3) { if (has_next) stage_piece(nxt, nb, p); }
             if (p & 1) {
@@ -1191,16 +1225,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist(const GemmArgs 
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
+            if (mh == 0 || !htile) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    // a tile's first products start from a literal zero C operand: no 128 v_mov per tile to clear the accumulators
-                    if (KIND == 0 && kh == 0)
-                        acc[mh * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                    else
-                        acc[mh * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[mh * 4 + i][j], 0, 0, 0);
-                }
+                    for (int j = 0; j < 4; ++j) {
+                        // a tile's first products start from a literal zero C operand: no 128 v_mov per tile to clear the accumulators
+                        if (KIND == 0 && kh == 0)
+                            acc[mh * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                        else
+                            acc[mh * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[mh * 4 + i][j], 0, 0, 0);
+                    }
+            }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
@@ -1250,8 +1286,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist(const GemmArgs 
         const bool edge = (m0 + BM > g.M) || (n0 + BN > g.N);      // an edge tile issues fewer than 16 stores per wave
         if (wst != nullptr && lane == 0) wst[1] = __builtin_amdgcn_s_memtime();
         if (g.epi_prio && wm == 1) __builtin_amdgcn_s_setprio(1);
-        if (DIRECT) epilogue_stream<EPI, FOLD, MAPPED, KEEP, STATS>(g, acc, smem + PRM_OFF + pslot * 4096, m0, n0, wave, lane, edge, wst, smem + IMG_OFF);
-        else epilogue_stream_lds<EPI, FOLD, MAPPED>(g, acc, smem + IMG_OFF + wave * 2048, smem + PRM_OFF + pslot * 4096, m0, n0, wave, lane, edge, wst);
+        if (DIRECT) epilogue_stream<EPI, FOLD, MAPPED, KEEP, STATS>(g, acc, smem + PRM_OFF + pslot * 4096, m0, n0, wave, lane, edge, wst, htile, smem + IMG_OFF);
+        else epilogue_stream_lds<EPI, FOLD, MAPPED>(g, acc, smem + IMG_OFF + wave * 2048, smem + PRM_OFF + pslot * 4096, m0, n0, wave, lane, edge, wst, htile);
         if (g.epi_prio && wm == 1) __builtin_amdgcn_s_setprio(0);
         stamp(3);
         ++titer;
@@ -1283,6 +1319,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist(const GemmArgs 
         pslot ^= 1;
         cur = nxt;
         m0 = nm0; n0 = nn0;
+        set_lanes(n0);
         tcur = tnext;
     }
 }
@@ -1553,6 +1590,15 @@ int launch(GemmArgs a, hipStream_t st) {
     } else {
         const int ncu = num_cus();
         const dim3 grid(nwg < ncu ? nwg : ncu), blk(NTHREADS);
+        {   // half last n-tile under the plain walk: balance it across the workgroups (GemmArgs::rotmask)
+            const int rem = a.N % BN, nper = (int)grid.x >> 3;
+            static int rot_env = -1;
+            if (rot_env < 0) { const char* e = getenv("OVHIP_GEMM_ROTATE"); rot_env = (e && e[0] == '0') ? 0 : 1; }
+            a.rotmask = 0;
+            if (rot_env && rem > 0 && rem <= 128 && a.ngroup >= a.tiles_n && a.tiles_n > 1 && (a.tiles_n & (a.tiles_n - 1)) == 0 &&
+                grid.x % 8 == 0 && nper % a.tiles_n == 0)
+                a.rotmask = a.tiles_n - 1;
+        }
         // Epilogue form.  GELU and residual epilogues: row-per-lane direct stores (no LDS round trip; the LDS form of these two
         // needs more than the 256 VGPRs a wave has here and spills, which the hand-counted waits cannot tolerate).  Bias-only
         // epilogue (QKV, projections): LDS-transposed coalesced stores measure faster in the model (9.5-9.8 against 10.0-10.3 ms per
@@ -1617,7 +1663,7 @@ extern "C" int ov_gemm(const ov_bf16* A, int64_t lda, const ov_bf16* W, int64_t 
     if (tiles_m * tiles_n > 0x7fffffffLL || M > 0x7fff0000LL) return OV_ERR_UNSUPPORTED;    // 32-bit row indices in the kernels
     GemmArgs a{A, W, bias, C, R, lda, ldw, ldc, ldr, M, N, K, (int)tiles_m, (int)tiles_n,
                out_group, resid_mod, resid_off, g_colsum, g_rowstats, g_stamps, g_stamp_slots, g_wstamps, gemm_ngroup((int)tiles_m, (int)tiles_n, K), 0, 0, 0,
-               gemm_stagger(K), gemm_stagger_classes(), gemm_epi_prio(), g_keep, g_ldkeep, nullptr, g_rowpart};
+               gemm_stagger(K), gemm_stagger_classes(), gemm_epi_prio(), g_keep, g_ldkeep, nullptr, 0, g_rowpart};
     hipStream_t st = (hipStream_t)stream;
     switch (epilogue) {
         case OV_EPI_BIAS: return launch<OV_EPI_BIAS>(a, st);

@@ -730,7 +730,8 @@ def test_gemm_tn_matches_transposed_operands(Mc, NI, NJ, chunk):
     assert torch.equal(got, ref2)
 
 
-@pytest.mark.parametrize("M,N,K", [(65535, 1024, 1024), (65792, 1024, 256), (257, 1024, 4096), (1500, 768, 320), (12336, 1024, 256), (300, 192, 192)])
+@pytest.mark.parametrize("M,N,K", [(65535, 1024, 1024), (65792, 1024, 256), (257, 1024, 4096), (1500, 768, 320), (12336, 1024, 256), (300, 192, 192),
+                                   (66000, 384, 256)])
 def test_gemm_rowparts_are_the_row_partial_sums_of_the_output(M, N, K):
     """ov_gemm_rowparts: the residual GEMM leaves {sum, sum of squares} of every 32-column group of its OUTPUT rows -- from the
     persistent kernel's epilogue (first two shapes: whole tiles and a ragged last row tile), from the skinny kernel's (M = 257, 300,
@@ -772,11 +773,16 @@ sys.path.insert(0, os.environ["OV_ROOT"]); sys.path.insert(0, os.path.join(os.en
 import hipops as H
 g = torch.Generator().manual_seed(3)
 outs = []
-for (M, N, K) in ((2048, 1024, 256), (65792, 1024, 256), (1500, 776, 320)):
+# (the last three: a last n-tile with <= 128 valid columns -- the persistent kernel's half tiles, rotated walk at tiles_n = 2)
+for (M, N, K) in ((2048, 1024, 256), (65792, 1024, 256), (1500, 776, 320), (70001, 384, 384), (66000, 1152, 192), (66100, 632, 256)):
     a = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda(); w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).cuda()
     b = torch.randn(N, generator=g).cuda(); r = torch.randn(M, N, generator=g).to(torch.bfloat16).cuda()
     for epi in (0, 1, 2, 3, 4):
         outs.append(H.gemm(a, w, b, epi=epi, resid=r if epi >= 3 else None).cpu())
+    if N in (384, 1152):                       # the LN-folded forms (QKV: LDS-transposed stores; c_fc: direct stores)
+        st = H.rowstats(a); cs = w.float().sum(1)
+        for epi in (0, 1):
+            outs.append(H.gemm_ln(a, w, b, cs, st, epi=epi).cpu())
 torch.save(outs, sys.argv[1])
 """
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -787,6 +793,6 @@ torch.save(outs, sys.argv[1])
             env = dict(os.environ, OVHIP_GEMM_VARIANT=v, OV_ROOT=root)
             subprocess.run([sys.executable, "-c", code, path], check=True, env=env, timeout=600)
             res[v] = torch.load(path)
-    assert len(res["0"]) == 15
+    assert len(res["0"]) == 34
     for i, (x, y) in enumerate(zip(res["0"], res[variant])):
         assert torch.equal(x, y), (variant, i)
