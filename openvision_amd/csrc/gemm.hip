@@ -43,6 +43,7 @@ struct GemmArgs {
     int epi_prio;                        // persistent kernel: n > 0: waves 4-7 (the arbitration losers) run epilogue passes < n at s_setprio 1
     ov_bf16* C2; int64_t ldc2;           // ov_gemm_keep: second output = the GELU epilogue's pre-activation (acc + bias), bf16
     float* psum;                         // gemm_bf16_pp_tn: [gridDim.y][M] column sums of P over the split's rows (NULL = off)
+    int rev;                             // persistent kernel: walk the row tiles from the last to the first (see gemm_reverse)
     int rotmask;                         // persistent kernel, plain walk, half last n-tile (see HALF TILES): tiles_n - 1 when the workgroup
                                          // stride is a multiple of tiles_n -- the n index is then rotated by the workgroup's tile count, so
                                          // that every workgroup alternates between full and half tiles (0 = off)
@@ -1074,7 +1075,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist(const GemmArgs 
         const int schunk = (tid_f & 3) ^ swz4(srow);
         // (rotated walk: this workgroup's k-th tile takes n index (d0 + k) mod tiles_n; its d0 never changes, the stride being a
         // multiple of tiles_n, and the tiles_n workgroups that share a row panel in a round hold distinct d0)
-        const int tm = p0 + d1, tn = g.rotmask ? ((d0 + rotk) & g.rotmask) : d2 * rad0 + d0;
+        const int tmf = p0 + d1;
+        const int tm = g.rev ? g.tiles_m - 1 - tmf : tmf, tn = g.rotmask ? ((d0 + rotk) & g.rotmask) : d2 * rad0 + d0;
         ++rotk;
         d0 += s0;
         if (d0 >= rad0) { d0 -= rad0; ++d1; }
@@ -1595,6 +1597,9 @@ int launch(GemmArgs a, hipStream_t st) {
             static int rot_env = -1;
             if (rot_env < 0) { const char* e = getenv("OVHIP_GEMM_ROTATE"); rot_env = (e && e[0] == '0') ? 0 : 1; }
             a.rotmask = 0;
+            static int rev_env = -1;
+            if (rev_env < 0) { const char* e = getenv("OVHIP_GEMM_REVERSE"); rev_env = e ? atoi(e) : 0; }
+            a.rev = (rev_env >> (EPI < 4 ? EPI : 3)) & 1;           // experiment: bit e = reverse the launches with epilogue e
             if (rot_env && rem > 0 && rem <= 128 && a.ngroup >= a.tiles_n && a.tiles_n > 1 && (a.tiles_n & (a.tiles_n - 1)) == 0 &&
                 grid.x % 8 == 0 && nper % a.tiles_n == 0)
                 a.rotmask = a.tiles_n - 1;
@@ -1663,7 +1668,7 @@ extern "C" int ov_gemm(const ov_bf16* A, int64_t lda, const ov_bf16* W, int64_t 
     if (tiles_m * tiles_n > 0x7fffffffLL || M > 0x7fff0000LL) return OV_ERR_UNSUPPORTED;    // 32-bit row indices in the kernels
     GemmArgs a{A, W, bias, C, R, lda, ldw, ldc, ldr, M, N, K, (int)tiles_m, (int)tiles_n,
                out_group, resid_mod, resid_off, g_colsum, g_rowstats, g_stamps, g_stamp_slots, g_wstamps, gemm_ngroup((int)tiles_m, (int)tiles_n, K), 0, 0, 0,
-               gemm_stagger(K), gemm_stagger_classes(), gemm_epi_prio(), g_keep, g_ldkeep, nullptr, 0, g_rowpart};
+               gemm_stagger(K), gemm_stagger_classes(), gemm_epi_prio(), g_keep, g_ldkeep, nullptr, 0, 0, g_rowpart};
     hipStream_t st = (hipStream_t)stream;
     switch (epilogue) {
         case OV_EPI_BIAS: return launch<OV_EPI_BIAS>(a, st);

@@ -100,11 +100,12 @@ def gemm_rowparts(a, w, bias, resid, out=None):
     return out, parts
 
 
-def gemm_ln(x, wg, cvec, colsum, stats, epi=0):
+def gemm_ln(x, wg, cvec, colsum, stats, epi=0, out=None):
     lib = _lib.load()
     m, k = x.shape
     n = wg.shape[0]
-    out = torch.empty(m, n, dtype=torch.bfloat16, device=x.device)
+    if out is None:
+        out = torch.empty(m, n, dtype=torch.bfloat16, device=x.device)
     check(lib.ov_gemm_ln(ptr(x), x.stride(0), ptr(wg), wg.stride(0), ptr(cvec), ptr(colsum), ptr(stats), ptr(out), out.stride(0),
                          m, n, k, epi, stream_ptr()))
     return out
