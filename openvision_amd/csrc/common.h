@@ -265,6 +265,9 @@ __device__ __forceinline__ float add_rowpair_even_first(float x) {
 #ifndef OVHIP_ST_DIRECT
 #define OVHIP_ST_DIRECT 2       /* policy of the direct (row-per-lane, half-line) epilogue's stores */
 #endif
+#ifndef OVHIP_ST_RESID
+#define OVHIP_ST_RESID 0        /* residual epilogues: the output is the residual stream itself, re-read at once -- plain (45.46 -> 45.35 ms at L/14) */
+#endif
 template <int POLICY>
 __device__ __forceinline__ void store16(void* dst, u32x4_t v) {
     if (POLICY == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(dst), "v"(v) : "memory");

@@ -43,6 +43,8 @@ struct GemmArgs {
     int epi_prio;                        // persistent kernel: n > 0: waves 4-7 (the arbitration losers) run epilogue passes < n at s_setprio 1
     ov_bf16* C2; int64_t ldc2;           // ov_gemm_keep: second output = the GELU epilogue's pre-activation (acc + bias), bf16
     float* psum;                         // gemm_bf16_pp_tn: [gridDim.y][M] column sums of P over the split's rows (NULL = off)
+    int st_plain;                        // persistent kernel, bias / GELU epilogues: plain instead of streaming output stores (small outputs)
+    int half_ok;                         // persistent kernel: half tiles allowed (OVHIP_GEMM_HALF=0 switches them off)
     int rev;                             // persistent kernel: walk the row tiles from the last to the first (launcher: c_proj)
     int rotmask;                         // persistent kernel, plain walk, half last n-tile (see HALF TILES): tiles_n - 1 when the workgroup
                                          // stride is a multiple of tiles_n -- the n index is then rotated by the workgroup's tile count, so
@@ -681,7 +683,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {          // lite
 // groups per wave: common.h) and leaves them in an LDS image of the tile; gemm_bf16_persist writes the image out behind the tile
 // barrier.  The next LayerNorm's row pass (a re-read of the whole residual stream, 1.5 ms of the L/14 step) shrinks to a pass over
 // these sums.
-template <int EPI, bool FOLD, bool MAPPED, bool KEEP = false, bool STATS = false>
+template <int EPI, bool FOLD, bool MAPPED, bool KEEP = false, bool STATS = false, int ST = OVHIP_ST_DIRECT>
 __device__ __forceinline__ void epilogue_stream(const GemmArgs& g, f32x4_t (&acc)[8][4], const char* prm,
                                                 int64_t m0, int n0, int wave, int lane, bool edge, unsigned long long* wst,
                                                 bool htile, char* stats_lds = nullptr) {
@@ -769,7 +771,7 @@ __device__ __forceinline__ void epilogue_stream(const GemmArgs& g, f32x4_t (&acc
         for (int h = 0; h < 2; ++h) {
             u32x4_t o = vo[i][h];
             if (EPI >= OV_EPI_BIAS_RESIDUAL) o = epi_combine<EPI>(o, rv[i][h]);
-            if (m < (unsigned)g.M && (h ? ncol1 : ncol0) && live) store16<OVHIP_ST_DIRECT>(dst + h * 32, o);
+            if (m < (unsigned)g.M && (h ? ncol1 : ncol0) && live) store16<(EPI >= OV_EPI_BIAS_RESIDUAL) ? OVHIP_ST_RESID : ST>(dst + h * 32, o);
             if (STATS) {
                 // this lane's 8 consecutive columns -> octet; fq 0 | 2 | 1 | 3 hold octets 0 | 1 | 2 | 3 of the 32-column group
                 float s8, q8;
@@ -832,7 +834,7 @@ __device__ __forceinline__ void epilogue_stream(const GemmArgs& g, f32x4_t (&acc
             for (int h = 0; h < 2; ++h) {
                 const u32x2_t s0 = __builtin_amdgcn_permlane16_swap(pk2[2 * h][0], pk2[2 * h + 1][0], false, false);
                 const u32x2_t s1 = __builtin_amdgcn_permlane16_swap(pk2[2 * h][1], pk2[2 * h + 1][1], false, false);
-                if (m < (unsigned)g.M && (h ? ncol1 : ncol0) && (i < 4 || !htile)) store16<OVHIP_ST_DIRECT>(dst2 + h * 32, u32x4_t{s0[0], s1[0], s0[1], s1[1]});
+                if (m < (unsigned)g.M && (h ? ncol1 : ncol0) && (i < 4 || !htile)) store16<ST>(dst2 + h * 32, u32x4_t{s0[0], s1[0], s0[1], s1[1]});
             }
         }
 #pragma unroll
@@ -859,7 +861,7 @@ __device__ __forceinline__ void epilogue_stream(const GemmArgs& g, f32x4_t (&acc
 
 // The same epilogue with the 16-byte stores made row-contiguous through a wave-local LDS image (8 lanes x 16 B = one 128-B line):
 // coalesced stores (16 TA cycles per instruction against ~70 for the row-per-lane form above), at the price of the LDS round trip.
-template <int EPI, bool FOLD, bool MAPPED>
+template <int EPI, bool FOLD, bool MAPPED, int ST = OVHIP_ST_LDS>
 __device__ __forceinline__ void epilogue_stream_lds(const GemmArgs& g, f32x4_t (&acc)[8][4], char* img, const char* prm,
                                                 int64_t m0, int n0, int wave, int lane, bool edge, unsigned long long* wst, bool htile) {
     const int wm = wave >> 2;
@@ -929,12 +931,12 @@ __device__ __forceinline__ void epilogue_stream_lds(const GemmArgs& g, f32x4_t (
             const unsigned m = (unsigned)m0 + rb + i * 16 + it * 8 + er;
             const bool live = i < 4 || !htile;
             if (!MAPPED) {   // no row map: the lane's row pointer of pass 0, stepped by whole rows
-                if (m < (unsigned)g.M && ncol && live) store16<OVHIP_ST_LDS>(cbase_lds + (int64_t)(i * 16 + it * 8) * g.ldc, o);
+                if (m < (unsigned)g.M && ncol && live) store16<(EPI >= OV_EPI_BIAS_RESIDUAL) ? OVHIP_ST_RESID : ST>(cbase_lds + (int64_t)(i * 16 + it * 8) * g.ldc, o);
                 continue;
             }
             if (m < (unsigned)g.M && ncol && live) {
                 const unsigned orow = g.out_group ? m + m / (unsigned)g.out_group + 1 : m;
-                store16<OVHIP_ST_LDS>(g.C + (int64_t)orow * g.ldc + n, o);
+                store16<(EPI >= OV_EPI_BIAS_RESIDUAL) ? OVHIP_ST_RESID : ST>(g.C + (int64_t)orow * g.ldc + n, o);
             }
         }
     };
@@ -1150,7 +1152,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist(const GemmArgs 
     bool htile;
     int a_lane, w_lane;
     auto set_lanes = [&](int nn) {
-        htile = g.N - nn <= 128;
+        htile = g.half_ok && g.N - nn <= 128;
         const int lf = fresh_lane();
         const int fr = lf & 15, fq = lf >> 4;
         const int lsw = (fq ^ swz4(fr)) << 4;
@@ -1288,8 +1290,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_bf16_persist(const GemmArgs 
         const bool edge = (m0 + BM > g.M) || (n0 + BN > g.N);      // an edge tile issues fewer than 16 stores per wave
         if (wst != nullptr && lane == 0) wst[1] = __builtin_amdgcn_s_memtime();
         if (g.epi_prio && wm == 1) __builtin_amdgcn_s_setprio(1);
-        if (DIRECT) epilogue_stream<EPI, FOLD, MAPPED, KEEP, STATS>(g, acc, smem + PRM_OFF + pslot * 4096, m0, n0, wave, lane, edge, wst, htile, smem + IMG_OFF);
-        else epilogue_stream_lds<EPI, FOLD, MAPPED>(g, acc, smem + IMG_OFF + wave * 2048, smem + PRM_OFF + pslot * 4096, m0, n0, wave, lane, edge, wst, htile);
+        // Store policy by the size of the output (launcher): streaming (nt) stores keep a wide activation (qkv, hidden: 0.4-0.9 GB at
+        // the benchmark shapes) from displacing the operands in L2; an output that fits the 256 MB Infinity Cache is stored plainly so
+        // that its consumer finds it there (Ti/16: 6.68 -> 6.42 ms per step).  The residual forms always store plainly (x is re-read
+        // at once by the row statistics and the next GEMM).  Two inlined copies of the epilogue, one wave-uniform branch per tile.
+        constexpr bool DUAL = EPI < OV_EPI_BIAS_RESIDUAL;
+        if (DIRECT) {
+            if (DUAL && g.st_plain) epilogue_stream<EPI, FOLD, MAPPED, KEEP, STATS, 0>(g, acc, smem + PRM_OFF + pslot * 4096, m0, n0, wave, lane, edge, wst, htile, smem + IMG_OFF);
+            else epilogue_stream<EPI, FOLD, MAPPED, KEEP, STATS, OVHIP_ST_DIRECT>(g, acc, smem + PRM_OFF + pslot * 4096, m0, n0, wave, lane, edge, wst, htile, smem + IMG_OFF);
+        } else {
+            if (DUAL && g.st_plain) epilogue_stream_lds<EPI, FOLD, MAPPED, 0>(g, acc, smem + IMG_OFF + wave * 2048, smem + PRM_OFF + pslot * 4096, m0, n0, wave, lane, edge, wst, htile);
+            else epilogue_stream_lds<EPI, FOLD, MAPPED, OVHIP_ST_LDS>(g, acc, smem + IMG_OFF + wave * 2048, smem + PRM_OFF + pslot * 4096, m0, n0, wave, lane, edge, wst, htile);
+        }
         if (g.epi_prio && wm == 1) __builtin_amdgcn_s_setprio(0);
         stamp(3);
         ++titer;
@@ -1597,6 +1609,12 @@ int launch(GemmArgs a, hipStream_t st) {
             static int rot_env = -1;
             if (rot_env < 0) { const char* e = getenv("OVHIP_GEMM_ROTATE"); rot_env = (e && e[0] == '0') ? 0 : 1; }
             a.rotmask = 0;
+            static int half_env = -1;
+            if (half_env < 0) { const char* e = getenv("OVHIP_GEMM_HALF"); half_env = (e && e[0] == '0') ? 0 : 1; }
+            a.half_ok = half_env;
+            static int64_t nt_min = -1;                          // outputs of at least this many bytes are streamed (OVHIP_GEMM_NT_MIN_MB)
+            if (nt_min < 0) { const char* e = getenv("OVHIP_GEMM_NT_MIN_MB"); nt_min = (int64_t)(e ? atoi(e) : 192) << 20; }
+            a.st_plain = (int64_t)a.M * a.N * 2 < nt_min ? 1 : 0;
             // Row tiles from the last to the first for the residual GEMM that reads a wide hidden activation (c_proj: K >= 2 N): its
             // producer (c_fc) wrote the rows in ascending order, so the ones it wrote last are those the 256 MB Infinity Cache still
             // holds.  S/8@384 (906 MB hidden per layer) 35.03 -> 34.80 ms per step, L/14 (537 MB) 44.78 -> 44.70: small, free,
@@ -1604,7 +1622,7 @@ int launch(GemmArgs a, hipStream_t st) {
             static int rev_env = -1;
             if (rev_env < 0) { const char* e = getenv("OVHIP_GEMM_REVERSE"); rev_env = (e && e[0] == '0') ? 0 : 1; }
             a.rev = (rev_env && EPI == OV_EPI_BIAS_RESIDUAL && a.K >= 2 * a.N && a.out_group == 0 && a.resid_mod == 0) ? 1 : 0;
-            if (rot_env && rem > 0 && rem <= 128 && a.ngroup >= a.tiles_n && a.tiles_n > 1 && (a.tiles_n & (a.tiles_n - 1)) == 0 &&
+            if (rot_env && half_env && rem > 0 && rem <= 128 && a.ngroup >= a.tiles_n && a.tiles_n > 1 && (a.tiles_n & (a.tiles_n - 1)) == 0 &&
                 grid.x % 8 == 0 && nper % a.tiles_n == 0)
                 a.rotmask = a.tiles_n - 1;
         }
@@ -1672,7 +1690,7 @@ extern "C" int ov_gemm(const ov_bf16* A, int64_t lda, const ov_bf16* W, int64_t 
     if (tiles_m * tiles_n > 0x7fffffffLL || M > 0x7fff0000LL) return OV_ERR_UNSUPPORTED;    // 32-bit row indices in the kernels
     GemmArgs a{A, W, bias, C, R, lda, ldw, ldc, ldr, M, N, K, (int)tiles_m, (int)tiles_n,
                out_group, resid_mod, resid_off, g_colsum, g_rowstats, g_stamps, g_stamp_slots, g_wstamps, gemm_ngroup((int)tiles_m, (int)tiles_n, K), 0, 0, 0,
-               gemm_stagger(K), gemm_stagger_classes(), gemm_epi_prio(), g_keep, g_ldkeep, nullptr, 0, 0, g_rowpart};
+               gemm_stagger(K), gemm_stagger_classes(), gemm_epi_prio(), g_keep, g_ldkeep, nullptr, 0, 1, 0, 0, g_rowpart};
     hipStream_t st = (hipStream_t)stream;
     switch (epilogue) {
         case OV_EPI_BIAS: return launch<OV_EPI_BIAS>(a, st);
