@@ -126,7 +126,8 @@ __device__ __forceinline__ void epilogue_fp8(const Fp8Args& g, f32x4_t (&acc)[8]
                                        bf16hi_to_f32(o[e]) + bf16hi_to_f32(rv[i][it][e]));
             }
             const unsigned m = (unsigned)m0 + wm * 128 + i * 16 + it * 8 + er;
-            if (m < (unsigned)g.M && ncol) store16<OVHIP_ST_LDS>(g.C + (int64_t)m * g.ldc + n, o);
+            // (the residual form writes the residual stream, re-read at once: plain stores -- common.h, OVHIP_ST_RESID)
+            if (m < (unsigned)g.M && ncol) store16<(EPI == OV_EPI_BIAS_RESIDUAL) ? OVHIP_ST_RESID : OVHIP_ST_LDS>(g.C + (int64_t)m * g.ldc + n, o);
         }
     };
 #pragma unroll
