@@ -379,7 +379,7 @@ def main():
                        "gflop_per_pair": round(flops["pair"] / 1e9, 2),
                        "model_tflops_per_gpu": round(flops["pair"] * b * mb * a.steps / dt / 1e12, 1)},
             "loss": round(loss_val, 5),
-            "roofline": {"bound": "mfma", "kernel": (f"gemm_bf16_persist<1, true, true, false, false> (EPI erf-GELU, LN fold, direct stores)" if not fc_fp8
+            "roofline": {"bound": "mfma", "kernel": ("gemm_bf16_persist<1, true, true, false, false, false> (EPI erf-GELU, LN fold, direct stores)" if not fc_fp8
                                                      else "gemm_fp8_persist<1> (dequantise + bias + erf-GELU)")
                                    + f" = vision mlp.c_fc, N={int(Dv * cfg['vision_cfg']['mlp_ratio'])} K={Dv}, "
                                    f"M={int(rows.value / launches)} rows per launch",

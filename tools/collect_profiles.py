@@ -37,7 +37,8 @@ Mv_main = (batch - 1) * Lv            # the tower peels the last image onto a si
 PEAK_TF, PEAK_GBS = 2500.0, 8000.0
 # kernels whose per-launch algorithmic work is unambiguous on this workload (vision tower main part)
 known = {
-    "gemm_bf16_persist<1, true, true, false, false>": ("mfma", 2.0 * Mv_main * Fv * Dv, "vision mlp.c_fc (LN fold + erf-GELU, direct-store epilogue)"),
+    "gemm_bf16_persist<1, true, true, false, false, false>": ("mfma", 2.0 * Mv_main * Fv * Dv, "vision mlp.c_fc (LN fold + erf-GELU, direct-store epilogue)"),
+    "gemm_bf16_persist<1, true, true, false, false>": ("mfma", 2.0 * Mv_main * Fv * Dv, "vision mlp.c_fc (LN fold + erf-GELU, direct-store epilogue) [kernel name before the STATS parameter]"),
     "gemm_bf16_persist<1, true, true, false>": ("mfma", 2.0 * Mv_main * Fv * Dv, "vision mlp.c_fc (LN fold + erf-GELU, direct-store epilogue) [kernel name before the KEEP parameter]"),
     "gemm_bf16_persist<1, true, true>": ("mfma", 2.0 * Mv_main * Fv * Dv, "vision mlp.c_fc (LN fold + erf-GELU, direct-store epilogue) [earlier kernel name]"),
     "gemm_bf16_persist<1, true>": ("mfma", 2.0 * Mv_main * Fv * Dv, "vision mlp.c_fc (LN fold + erf-GELU) [round-1 kernel name]"),
