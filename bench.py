@@ -123,6 +123,16 @@ def dry_run_gloo(a, result_out) -> None:
         raise SystemExit("gathered rows are not in rank order")
 
 
+def fc_kernel_name(rows: int, n: int) -> str:
+    """The instantiation the library launches for the LN-folded erf-GELU c_fc GEMM (csrc/gemm.hip, launch<EPI>): outputs of at least
+    OVHIP_GEMM_NT_MIN_MB (192) MB are streamed and take the LDS-transposed epilogue, smaller ones the direct one."""
+    env = os.environ.get("OVHIP_GEMM_GELU_LDS")
+    big = rows * n * 2 >= int(os.environ.get("OVHIP_GEMM_NT_MIN_MB", "192")) << 20
+    lds = (env[0] == "1") if env else big
+    return ("gemm_bf16_persist<1, true, false, false, false, false> (EPI erf-GELU, LN fold, LDS-transposed whole-line stores)" if lds
+            else "gemm_bf16_persist<1, true, true, false, false, false> (EPI erf-GELU, LN fold, direct stores)")
+
+
 def comm_summary(comm_log, own_dt, steps, payload_bytes, world, dev):
     """What a first multi-GPU run needs to be diagnosed (every rank calls this: it holds two small collectives): the exchange step's
     own time inside the timed region (one all-gather of the packed [b, 2E] fp32 embeddings per step: event pairs on the launch
@@ -379,7 +389,7 @@ def main():
                        "gflop_per_pair": round(flops["pair"] / 1e9, 2),
                        "model_tflops_per_gpu": round(flops["pair"] * b * mb * a.steps / dt / 1e12, 1)},
             "loss": round(loss_val, 5),
-            "roofline": {"bound": "mfma", "kernel": ("gemm_bf16_persist<1, true, true, false, false, false> (EPI erf-GELU, LN fold, direct stores)" if not fc_fp8
+            "roofline": {"bound": "mfma", "kernel": (fc_kernel_name(int(rows.value / launches), int(Dv * cfg['vision_cfg']['mlp_ratio'])) if not fc_fp8
                                                      else "gemm_fp8_persist<1> (dequantise + bias + erf-GELU)")
                                    + f" = vision mlp.c_fc, N={int(Dv * cfg['vision_cfg']['mlp_ratio'])} K={Dv}, "
                                    f"M={int(rows.value / launches)} rows per launch",

@@ -1649,8 +1649,12 @@ int launch(GemmArgs a, hipStream_t st) {
             hipLaunchKernelGGL((gemm_bf16_persist<E, false, true, false, true>), grid, blk, 0, st, a);
         } else if (CAN_FOLD && a.colsum != nullptr) {
             // GELU with the LN fold (vision / text c_fc): OVHIP_GEMM_GELU_LDS=1 selects the LDS-transposed form (whole-line stores)
-            static int gelu_lds = -1;
-            if (gelu_lds < 0) { const char* e = getenv("OVHIP_GEMM_GELU_LDS"); gelu_lds = (e && e[0] == '1') ? 1 : 0; }
+            // Default: the LDS-transposed form when the output is streamed (whole 128-byte lines leave L2; the direct form's 16-byte
+            // streaming stores leave as partial lines: WRITE_SIZE 0.69 against 0.54 GB per L/14 launch) -- L/14 45.1 -> 44.9 ms, S/8
+            // 35.7 -> 35.4; the direct form for small, plainly stored outputs (Ti/16: 0.71 against 0.73 ms).  OVHIP_GEMM_GELU_LDS=0|1 forces.
+            static int gelu_env = -2;
+            if (gelu_env == -2) { const char* e = getenv("OVHIP_GEMM_GELU_LDS"); gelu_env = e ? (e[0] == '1' ? 1 : 0) : -1; }
+            const int gelu_lds = gelu_env >= 0 ? gelu_env : (a.st_plain ? 0 : 1);
             constexpr int EF = CAN_FOLD ? EPI : OV_EPI_BIAS_GELU_ERF;      // (the residual epilogues never come here: not instantiated)
             if (gelu_lds) hipLaunchKernelGGL((gemm_bf16_persist<EF, true, false, false>), grid, blk, 0, st, a);
             else hipLaunchKernelGGL((gemm_bf16_persist<EF, true, true, false>), grid, blk, 0, st, a);
