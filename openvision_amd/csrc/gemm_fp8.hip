@@ -21,6 +21,10 @@
 #include "common.h"
 #include <stdlib.h>
 
+#ifndef OVHIP_ST_FP8OUT
+#define OVHIP_ST_FP8OUT OVHIP_ST_LDS     /* store policy of the e4m3 output (64-byte row pieces: half lines) */
+#endif
+
 namespace {
 
 constexpr int BM = 256, BN = 256, BKB = 128;       // K-tile: 128 bytes of K per row
@@ -167,7 +171,7 @@ __device__ __forceinline__ void epilogue_fp8(const Fp8Args& g, f32x4_t (&acc)[8]
             if (i > 0) {
                 const unsigned m = (unsigned)m0 + wm * 128 + (i - 1) * 16 + (lane >> 2);
                 const int n8 = n0 + wn * 64 + (lane & 3) * 16;
-                if (m < (unsigned)g.M && n8 < g.N) store16<OVHIP_ST_LDS>((unsigned char*)g.C + (int64_t)m * g.ldc + n8, vo[i - 1][0]);
+                if (m < (unsigned)g.M && n8 < g.N) store16<OVHIP_ST_FP8OUT>((unsigned char*)g.C + (int64_t)m * g.ldc + n8, vo[i - 1][0]);
             }
             if (i < 8) vo[i][0] = *(const u32x4_t*)(img + (lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 3) & 3)) << 4));
         } else {
