@@ -872,7 +872,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_hd64_stream(const AttnSArgs a
 // the head padded to 96 in LDS (zero columns), 256-key chunks staged through registers, one key tile per step.  A plain,
 // correctness-first variant: these model sizes are not on the benchmark configuration.
 template <int HDP>
-__global__ __launch_bounds__(512, 2) void attn_fwd_generic(const AttnArgs a, int hd) {
+__global__ __launch_bounds__(640) void attn_fwd_generic(const AttnArgs a, int hd) {
     constexpr int KS = HDP / 16;           // k-steps of S^T = K.Q^T
     constexpr int DT = HDP / 32;           // 32-row tiles of O^T
     constexpr int CH = HDP / 8;            // 16-byte chunks per (padded) row
@@ -946,10 +946,15 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_generic(const AttnArgs a, int
                     if (key >= nk) s[i] = -INFINITY;
                 }
             }
-            float mx = s[0];
-#pragma unroll
-            for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s[i]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * a.scale_log2;
+            // (the maximum reads the accumulator from inline asm: the MFMA -> VALU wait states are not inserted in front of inline asm,
+            // and a full tile leaves no other instruction in between -- see the single-tile step of attn_fwd_hd64_persist)
+            asm volatile("s_nop 15" : "+v"(s));
+            float mx = max3_asm(max3_asm(s[0], s[1], s[2]), max3_asm(s[3], s[4], s[5]), max3_asm(s[6], s[7], s[8]));
+            mx = max3_asm(mx, max3_asm(s[9], s[10], s[11]), max3_asm(max3_asm(s[12], s[13], s[14]), s[15], s[15]));
+            {
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+                mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])) * a.scale_log2;
+            }
             if (!__all(mx - m <= 8.0f)) {
                 const float mn = fmaxf(m, mx);
                 const float alpha = __builtin_amdgcn_exp2f(m - mn);
@@ -961,13 +966,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_generic(const AttnArgs a, int
                     for (int i = 0; i < 16; ++i) o[t][i] *= alpha;
             }
             const float nm = -m;
-            float ps = 0.f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                s[i] = __builtin_amdgcn_exp2f(fmaf(s[i], a.scale_log2, nm));
-                ps += s[i];
-            }
-            lsum += ps;
+            f32x2_t ps = {0.f, 0.f};
+            exp_rows(s, a.scale_log2, nm, ps);
+            lsum += ps[0] + ps[1];
             bf16x8_t pf[2];
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
@@ -1051,8 +1052,12 @@ int attention_impl(const ov_bf16* qkv, int64_t ld_qkv, ov_bf16* out, int64_t ld_
         g.B = B; g.L = L; g.H = H; g.nqt = (L + 31) / 32; g.mode = 0;
         g.scale_log2 = scale * 1.4426950408889634f;
         const int lpad = g.nqt * 32;
-        g.KC = lpad < 256 ? lpad : 256;
-        const int nwg = g.nqt < 8 ? g.nqt : 8;
+        // up to 320 (padded) keys: the whole head resident in LDS (123 KB at 320) and one wave per query tile (<= 10), so a head is
+        // staged once by one workgroup (L = 257 used to take two 256-key chunks and a second workgroup for the 257th query row: So400m's
+        // attention 8.0 ms per step); longer sequences: 256-key chunks, 8 waves
+        const bool resident = lpad <= 320;
+        g.KC = resident ? lpad : 256;
+        const int nwg = resident ? g.nqt : 8;
         const size_t smem = (size_t)g.KC * 96 * 4;       // K (KC x 192 B) + V (3 x KC x 64 B)
         static OvPerDeviceOnce attr3;
         const int dev_attr3 = ov_current_device();

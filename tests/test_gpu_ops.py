@@ -122,8 +122,9 @@ def test_gemm_residual_inplace():
     np.testing.assert_allclose(xd.float().cpu().numpy(), ref.numpy(), rtol=1e-2, atol=2e-2)
 
 
-def test_gemm_patch_embed_row_maps():
-    B, g2, D, K = 3, 100, 192, 768
+@pytest.mark.parametrize("B,g2,D,K", [(3, 100, 192, 768), (700, 100, 384, 192)])
+def test_gemm_patch_embed_row_maps(B, g2, D, K):
+    """(the second shape: the persistent kernel with row maps, a half last n-tile and the rotated walk -- S/8's patch embedding at batch)"""
     a, w = rnd(B * g2, K, seed=17).to(torch.bfloat16), (rnd(D, K, seed=18) / K ** 0.5).to(torch.bfloat16)
     pos = rnd(g2 + 1, D, seed=19).to(torch.bfloat16)
     out = torch.zeros(B * (g2 + 1), D, dtype=torch.bfloat16, device=DEV)
