@@ -1558,6 +1558,32 @@ int gemm_epi_prio() {
     return v;
 }
 
+// Per-launch policy of the persistent kernel: half tiles and the rotated walk, store policy by output size, reverse row walk.
+inline int env_flag(const char* name, int dflt) {                 // "0" / "1" (anything else: the default)
+    const char* e = getenv(name);
+    return (e && (e[0] == '0' || e[0] == '1')) ? e[0] - '0' : dflt;
+}
+template <int EPI>
+void persist_policy(GemmArgs& a, int grid_x) {
+    static const int rot_env = env_flag("OVHIP_GEMM_ROTATE", 1), half_env = env_flag("OVHIP_GEMM_HALF", 1), rev_env = env_flag("OVHIP_GEMM_REVERSE", 1);
+    static const int64_t nt_min = [] { const char* e = getenv("OVHIP_GEMM_NT_MIN_MB"); return (int64_t)(e ? atoi(e) : 192) << 20; }();
+    a.half_ok = half_env;
+    // outputs of at least OVHIP_GEMM_NT_MIN_MB (192) MB are streamed, smaller ones stored plainly: their consumer finds them in the
+    // 256 MB Infinity Cache (gemm_bf16_persist, "Store policy")
+    a.st_plain = (int64_t)a.M * a.N * 2 < nt_min ? 1 : 0;
+    // Row tiles from the last to the first for the residual GEMM that reads a wide hidden activation (c_proj: K >= 2 N): its
+    // producer (c_fc) wrote the rows in ascending order, so the ones it wrote last are those the Infinity Cache still holds.
+    // S/8@384 (906 MB hidden per layer) 35.03 -> 34.80 ms per step, L/14 (537 MB) 44.78 -> 44.70: small, free, bitwise the same
+    // results.  OVHIP_GEMM_REVERSE=0 switches it off.
+    a.rev = (rev_env && EPI == OV_EPI_BIAS_RESIDUAL && a.K >= 2 * a.N && a.out_group == 0 && a.resid_mod == 0) ? 1 : 0;
+    // a half last n-tile under the plain walk with a workgroup stride that is a multiple of tiles_n: rotate (GemmArgs::rotmask)
+    const int rem = a.N % BN, nper = grid_x >> 3;
+    a.rotmask = 0;
+    if (rot_env && half_env && rem > 0 && rem <= 128 && a.ngroup >= a.tiles_n && a.tiles_n > 1 && (a.tiles_n & (a.tiles_n - 1)) == 0 &&
+        grid_x % 8 == 0 && nper % a.tiles_n == 0)
+        a.rotmask = a.tiles_n - 1;
+}
+
 template <int EPI>
 int launch(GemmArgs a, hipStream_t st) {
     int var = gemm_variant();
@@ -1604,32 +1630,11 @@ int launch(GemmArgs a, hipStream_t st) {
     } else {
         const int ncu = num_cus();
         const dim3 grid(nwg < ncu ? nwg : ncu), blk(NTHREADS);
-        {   // half last n-tile under the plain walk: balance it across the workgroups (GemmArgs::rotmask)
-            const int rem = a.N % BN, nper = (int)grid.x >> 3;
-            static int rot_env = -1;
-            if (rot_env < 0) { const char* e = getenv("OVHIP_GEMM_ROTATE"); rot_env = (e && e[0] == '0') ? 0 : 1; }
-            a.rotmask = 0;
-            static int half_env = -1;
-            if (half_env < 0) { const char* e = getenv("OVHIP_GEMM_HALF"); half_env = (e && e[0] == '0') ? 0 : 1; }
-            a.half_ok = half_env;
-            static int64_t nt_min = -1;                          // outputs of at least this many bytes are streamed (OVHIP_GEMM_NT_MIN_MB)
-            if (nt_min < 0) { const char* e = getenv("OVHIP_GEMM_NT_MIN_MB"); nt_min = (int64_t)(e ? atoi(e) : 192) << 20; }
-            a.st_plain = (int64_t)a.M * a.N * 2 < nt_min ? 1 : 0;
-            // Row tiles from the last to the first for the residual GEMM that reads a wide hidden activation (c_proj: K >= 2 N): its
-            // producer (c_fc) wrote the rows in ascending order, so the ones it wrote last are those the 256 MB Infinity Cache still
-            // holds.  S/8@384 (906 MB hidden per layer) 35.03 -> 34.80 ms per step, L/14 (537 MB) 44.78 -> 44.70: small, free,
-            // bitwise the same results.  OVHIP_GEMM_REVERSE=0 switches it off.
-            static int rev_env = -1;
-            if (rev_env < 0) { const char* e = getenv("OVHIP_GEMM_REVERSE"); rev_env = (e && e[0] == '0') ? 0 : 1; }
-            a.rev = (rev_env && EPI == OV_EPI_BIAS_RESIDUAL && a.K >= 2 * a.N && a.out_group == 0 && a.resid_mod == 0) ? 1 : 0;
-            if (rot_env && half_env && rem > 0 && rem <= 128 && a.ngroup >= a.tiles_n && a.tiles_n > 1 && (a.tiles_n & (a.tiles_n - 1)) == 0 &&
-                grid.x % 8 == 0 && nper % a.tiles_n == 0)
-                a.rotmask = a.tiles_n - 1;
-        }
-        // Epilogue form.  GELU and residual epilogues: row-per-lane direct stores (no LDS round trip; the LDS form of these two
-        // needs more than the 256 VGPRs a wave has here and spills, which the hand-counted waits cannot tolerate).  Bias-only
-        // epilogue (QKV, projections): LDS-transposed coalesced stores measure faster in the model (9.5-9.8 against 10.0-10.3 ms per
-        // step for the QKV GEMMs); OVHIP_GEMM_EPI_DIRECT=1 selects the direct form there too.
+        persist_policy<EPI>(a, (int)grid.x);
+        // Epilogue form.  Residual epilogues: row-per-lane direct stores (their LDS form needs more than the 256 VGPRs a wave has here
+        // and spills, which the hand-counted waits cannot tolerate).  Bias-only epilogue (QKV, projections): LDS-transposed coalesced
+        // stores measure faster in the model (9.5-9.8 against 10.0-10.3 ms per step for the QKV GEMMs); OVHIP_GEMM_EPI_DIRECT=1
+        // selects the direct form there too.  GELU (LN-folded c_fc): by store policy, below.
         constexpr bool CAN_FOLD = EPI < OV_EPI_BIAS_RESIDUAL;
         const bool mapped = a.out_group != 0 || a.resid_mod != 0;          // row maps: the patch embedding's GEMM only
         if (EPI == OV_EPI_BIAS) {
