@@ -1631,10 +1631,9 @@ int launch(GemmArgs a, hipStream_t st) {
         const int ncu = num_cus();
         const dim3 grid(nwg < ncu ? nwg : ncu), blk(NTHREADS);
         persist_policy<EPI>(a, (int)grid.x);
-        // Epilogue form.  Residual epilogues: row-per-lane direct stores (their LDS form needs more than the 256 VGPRs a wave has here
-        // and spills, which the hand-counted waits cannot tolerate).  Bias-only epilogue (QKV, projections): LDS-transposed coalesced
-        // stores measure faster in the model (9.5-9.8 against 10.0-10.3 ms per step for the QKV GEMMs); OVHIP_GEMM_EPI_DIRECT=1
-        // selects the direct form there too.  GELU (LN-folded c_fc): by store policy, below.
+        // Epilogue form.  Bias-only epilogue (QKV, projections): LDS-transposed coalesced stores measure faster in the model (9.5-9.8
+        // against 10.0-10.3 ms per step for the QKV GEMMs); OVHIP_GEMM_EPI_DIRECT=1 selects the direct form there too.  GELU (LN-folded
+        // c_fc): by store policy, below.  Residual: LDS-transposed (below); with row maps, kept pre-activations or row statistics: direct.
         constexpr bool CAN_FOLD = EPI < OV_EPI_BIAS_RESIDUAL;
         const bool mapped = a.out_group != 0 || a.resid_mod != 0;          // row maps: the patch embedding's GEMM only
         if (EPI == OV_EPI_BIAS) {
@@ -1669,7 +1668,12 @@ int launch(GemmArgs a, hipStream_t st) {
             hipLaunchKernelGGL((gemm_bf16_persist<OV_EPI_BIAS_RESIDUAL, false, true, false, false, true>), grid, blk, 0, st, a);
             stats_fused = true;
         } else {
-            hipLaunchKernelGGL((gemm_bf16_persist<EPI, false, true, false>), grid, blk, 0, st, a);
+            // Residual epilogue: the LDS-transposed form (whole-line stores, 16 instead of ~70 TA cycles per store instruction) since the
+            // register diet of round 3 made it fit (246 VGPRs, zero scratch): out-proj 4.26 -> 4.10 ms per L/14 step, step -0.5 %
+            // (Ti/16 -1.8 %); OVHIP_GEMM_RESID_LDS=0 selects the direct form again.
+            static const int resid_lds = env_flag("OVHIP_GEMM_RESID_LDS", 1);
+            if (EPI == OV_EPI_BIAS_RESIDUAL && resid_lds) hipLaunchKernelGGL((gemm_bf16_persist<OV_EPI_BIAS_RESIDUAL, false, false, false>), grid, blk, 0, st, a);
+            else hipLaunchKernelGGL((gemm_bf16_persist<EPI, false, true, false>), grid, blk, 0, st, a);
         }
     }
     OV_LAUNCH_CHECK();
