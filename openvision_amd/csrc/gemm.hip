@@ -1672,8 +1672,12 @@ int launch(GemmArgs a, hipStream_t st) {
             // register diet of round 3 made it fit (246 VGPRs, zero scratch): out-proj 4.26 -> 4.10 ms per L/14 step, step -0.5 %
             // (Ti/16 -1.8 %); OVHIP_GEMM_RESID_LDS=0 selects the direct form again.
             static const int resid_lds = env_flag("OVHIP_GEMM_RESID_LDS", 1);
-            if (EPI == OV_EPI_BIAS_RESIDUAL && resid_lds) hipLaunchKernelGGL((gemm_bf16_persist<OV_EPI_BIAS_RESIDUAL, false, false, false>), grid, blk, 0, st, a);
-            else hipLaunchKernelGGL((gemm_bf16_persist<EPI, false, true, false>), grid, blk, 0, st, a);
+            if constexpr (EPI >= OV_EPI_BIAS_RESIDUAL) {       // (residual and GELU-gradient epilogues: both read a second operand row-wise)
+                if (resid_lds) hipLaunchKernelGGL((gemm_bf16_persist<EPI, false, false, false>), grid, blk, 0, st, a);
+                else hipLaunchKernelGGL((gemm_bf16_persist<EPI, false, true, false>), grid, blk, 0, st, a);
+            } else {
+                hipLaunchKernelGGL((gemm_bf16_persist<EPI, false, true, false>), grid, blk, 0, st, a);
+            }
         }
     }
     OV_LAUNCH_CHECK();
