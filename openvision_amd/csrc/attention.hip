@@ -672,6 +672,7 @@ struct AttnSArgs {
     float scale_log2;
     const float* out_amax;        // OUT8 (see AttnPArgs)
     float* amax_next;
+    int lone_valu;                // 1: a single-key last chunk (L = 64 k + 1) is folded in on the VALU (OVHIP_ATTN_LONEKEY=0: a chunk step)
 };
 
 template <bool OUT8>
@@ -753,7 +754,13 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_hd64_stream(const AttnSArgs a
         return __builtin_bit_cast(bf16x8_t, w);
     };
 
-    for (int c = 0; c < nc; ++c) {
+    // L = 64 k + 1 (every ViT grid of a multiple of 8 plus the class token: 577, 1025, 2305): the last chunk holds ONE key.  It is staged
+    // like any other chunk but folded in on the VALU behind the loop (its K / V rows are row 0 of its ring slot), as the persistent
+    // kernel does for its single-key tile: a chunk step for it is a whole barrier + 16 MFMAs + 32 exps per lane (2.8 % of the launch at
+    // L = 2305).
+    const bool lone_key = a.lone_valu != 0 && (L & 63) == 1 && nc > 1;
+    const int nc_mfma = lone_key ? nc - 1 : nc;
+    for (int c = 0; c < nc_mfma; ++c) {
         if (c + 2 < nc) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else if (c + 1 < nc) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -827,7 +834,53 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_hd64_stream(const AttnSArgs a
         o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join(vu[4], vu[5]), pb1, o0, 0, 0, 0);
         o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_join(vu[6], vu[7]), pb1, o1, 0, 0, 0);
     }
+    if (lone_key) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the last chunk's two pieces (issued three chunks ago)
+        asm volatile("s_barrier" ::: "memory");
+    }
     if (!active) return;
+    if (lone_key) {
+        const char* ks = smem + ((nc - 1) & 3) * 16384;           // key L-1 = row 0 of the slot: K chunk c at byte 16 c, V d-half h at 8192 + 4096 h
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const u32x4_t kq = *(const u32x4_t*)(ks + (2 * st + h2) * 16), qq = __builtin_bit_cast(u32x4_t, qf[st]);
+            asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(s0) : "v"(qq[0]), "v"(kq[0]));
+            asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(s1) : "v"(qq[1]), "v"(kq[1]));
+            asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(s0) : "v"(qq[2]), "v"(kq[2]));
+            asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(s1) : "v"(qq[3]), "v"(kq[3]));
+        }
+        asm("s_nop 2" : "+v"(s0), "+v"(s1));                      // DOT result -> ordinary VALU read (not inserted inside inline asm)
+        float sd = s0 + s1;                                       // this lane's half of d; the other half sits in lane ^ 32
+        {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(sd), __float_as_uint(sd), false, false);
+            sd = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        }
+        const float mx = sd * a.scale_log2;
+        if (!__all(mx - m <= 8.0f)) {
+            const float mn = fmaxf(m, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m - mn);
+            m = mn;
+            lsum *= alpha;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+        }
+        const float pk = __builtin_amdgcn_exp2f(mx - m);
+        lsum += h2 ? 0.f : pk;                                    // the halves' sums are added below: count the key once
+        const char* vrow = ks + 8192 + 8 * h2;                    // o0[4 g + e]: d = 8 g + 4 h2 + e; o1: + 32 (the other d-half)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const u32x2_t v0 = *(const u32x2_t*)(vrow + g * 16), v1 = *(const u32x2_t*)(vrow + 4096 + g * 16);
+            o0[4 * g + 0] = fmaf(pk, bf16lo_to_f32(v0[0]), o0[4 * g + 0]);
+            o0[4 * g + 1] = fmaf(pk, bf16hi_to_f32(v0[0]), o0[4 * g + 1]);
+            o0[4 * g + 2] = fmaf(pk, bf16lo_to_f32(v0[1]), o0[4 * g + 2]);
+            o0[4 * g + 3] = fmaf(pk, bf16hi_to_f32(v0[1]), o0[4 * g + 3]);
+            o1[4 * g + 0] = fmaf(pk, bf16lo_to_f32(v1[0]), o1[4 * g + 0]);
+            o1[4 * g + 1] = fmaf(pk, bf16hi_to_f32(v1[0]), o1[4 * g + 1]);
+            o1[4 * g + 2] = fmaf(pk, bf16lo_to_f32(v1[1]), o1[4 * g + 2]);
+            o1[4 * g + 3] = fmaf(pk, bf16hi_to_f32(v1[1]), o1[4 * g + 3]);
+        }
+    }
     float l;
     {
         const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lsum), __float_as_uint(lsum), false, false);
@@ -1133,6 +1186,7 @@ int attention_impl(const ov_bf16* qkv, int64_t ld_qkv, ov_bf16* out, int64_t ld_
         sa.scale_log2 = a.scale_log2;
         sa.out_amax = out_amax;
         sa.amax_next = amax_next;
+        { static int lk = -1; if (lk < 0) { const char* e = getenv("OVHIP_ATTN_LONEKEY"); lk = (e && e[0] == '0') ? 0 : 1; } sa.lone_valu = lk; }
         static OvPerDeviceOnce attr4;
         const int dev_attr4 = ov_current_device();
         if (attr4.need(dev_attr4)) {
