@@ -981,7 +981,10 @@ __global__ __launch_bounds__(640) void attn_fwd_generic(const AttnArgs a, int hd
         __syncthreads();
         if (!active) continue;
         const int nk = (L - kc0) < KC ? (L - kc0) : KC;
-        const int ntile = (nk + 31) >> 5;
+        // a last key tile that holds ONE key (L = 32 k + 1: 257) is folded in on the VALU behind the tile loop, as in the head_dim 64
+        // kernels: a tile step for it is a ninth of the loop at L = 257
+        const bool lone_key = (nk & 31) == 1 && nk > 32;
+        const int ntile = ((nk + 31) >> 5) - (lone_key ? 1 : 0);
         for (int kt = 0; kt < ntile; ++kt) {
             f32x16_t s;
 #pragma unroll
@@ -1036,6 +1039,50 @@ __global__ __launch_bounds__(640) void attn_fwd_generic(const AttnArgs a, int hd
                 for (int t = 0; t < DT; ++t) {
                     const char* v0 = vp + t * (KC * 64) + st * 16 * 64;
                     o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_pair(v0, v0 + 8 * 64), pf[st], o[t], 0, 0, 0);
+                }
+            }
+        }
+        if (lone_key) {
+            const int key = nk - 1;                                   // row of the chunk
+            const char* kp = ks + key * (HDP * 2) + h2 * 16;
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int st = 0; st < KS; ++st) {
+                const u32x4_t kq = *(const u32x4_t*)(kp + st * 32), qq = __builtin_bit_cast(u32x4_t, qf[st]);
+                asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(s0) : "v"(qq[0]), "v"(kq[0]));
+                asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(s1) : "v"(qq[1]), "v"(kq[1]));
+                asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(s0) : "v"(qq[2]), "v"(kq[2]));
+                asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(s1) : "v"(qq[3]), "v"(kq[3]));
+            }
+            asm("s_nop 2" : "+v"(s0), "+v"(s1));                      // DOT result -> ordinary VALU read (not inserted inside inline asm)
+            float sd = s0 + s1;                                       // this lane's d chunks; the others sit in lane ^ 32
+            {
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(sd), __float_as_uint(sd), false, false);
+                sd = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+            }
+            const float mx = sd * a.scale_log2;
+            if (!__all(mx - m <= 8.0f)) {
+                const float mn = fmaxf(m, mx);
+                const float alpha = __builtin_amdgcn_exp2f(m - mn);
+                m = mn;
+                lsum *= alpha;
+#pragma unroll
+                for (int t = 0; t < DT; ++t)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) o[t][i] *= alpha;
+            }
+            const float pk = __builtin_amdgcn_exp2f(mx - m);
+            lsum += h2 ? 0.f : pk;                                    // the halves' sums are added at the end: count the key once
+#pragma unroll
+            for (int t = 0; t < DT; ++t) {                            // o[t][4 g + e]: d = 32 t + 8 g + 4 h2 + e
+                const char* vrow = vs + t * (KC * 64) + key * 64 + 8 * h2;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const u32x2_t v = *(const u32x2_t*)(vrow + g * 16);
+                    o[t][4 * g + 0] = fmaf(pk, bf16lo_to_f32(v[0]), o[t][4 * g + 0]);
+                    o[t][4 * g + 1] = fmaf(pk, bf16hi_to_f32(v[0]), o[t][4 * g + 1]);
+                    o[t][4 * g + 2] = fmaf(pk, bf16lo_to_f32(v[1]), o[t][4 * g + 2]);
+                    o[t][4 * g + 3] = fmaf(pk, bf16hi_to_f32(v[1]), o[t][4 * g + 3]);
                 }
             }
         }
