@@ -776,7 +776,8 @@ g = torch.Generator().manual_seed(3)
 outs = []
 # (the last three: a last n-tile with <= 128 valid columns -- the persistent kernel's half tiles, rotated walk at tiles_n = 2)
 for (M, N, K) in ((2048, 1024, 256), (65792, 1024, 256), (1500, 776, 320), (70001, 384, 384), (66000, 1152, 192), (66100, 632, 256),
-                  (70000, 128, 192), (66000, 72, 256)):        # (a single n-tile that is a half tile)
+                  (70000, 128, 192), (66000, 72, 256),         # (a single n-tile that is a half tile)
+                  (66000, 256, 512)):                           # (K >= 2 N: the residual epilogue walks the row tiles in descending order)
     a = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda(); w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).cuda()
     b = torch.randn(N, generator=g).cuda(); r = torch.randn(M, N, generator=g).to(torch.bfloat16).cuda()
     for epi in (0, 1, 2, 3, 4):
@@ -795,6 +796,6 @@ torch.save(outs, sys.argv[1])
             env = dict(os.environ, OVHIP_GEMM_VARIANT=v, OV_ROOT=root)
             subprocess.run([sys.executable, "-c", code, path], check=True, env=env, timeout=600)
             res[v] = torch.load(path)
-    assert len(res["0"]) == 44
+    assert len(res["0"]) == 49
     for i, (x, y) in enumerate(zip(res["0"], res[variant])):
         assert torch.equal(x, y), (variant, i)
